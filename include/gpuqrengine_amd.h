@@ -1,0 +1,133 @@
+/* C ABI of the MI355X multifrontal QR front-batch engine (libgpuqrengine_amd.so).
+ *
+ * These are the symbols a foreign-function binding (or the C++ shim in
+ * GPUQREngine.hpp next to this file) binds in place of the reference's C++
+ * overloads.  Plain pointers and sizes only.  Every function is callable from
+ * C; none throws.  All sizes/indices are 64-bit like the reference's
+ * Int = SuiteSparse_long (GPUQREngine/Include/GPUQREngine_Common.hpp:64).
+ */
+#ifndef GPUQRENGINE_AMD_H
+#define GPUQRENGINE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* result codes, same values and meaning as QREngineResultCode
+ * (GPUQREngine/Include/GPUQREngine.hpp:17-22) */
+enum
+{
+    GPUQR_SUCCESS     = 0,
+    GPUQR_OUTOFMEMORY = 1,
+    GPUQR_GPUERROR    = 2
+};
+
+/* One entry of the packed S list: F[findex] = value.  Same 16-byte layout as
+ * SEntry (GPUQREngine/Include/GPUQREngine_SEntry.hpp:13-23). */
+typedef struct gpuqr_sentry
+{
+    int64_t findex;
+    double  value;
+} gpuqr_sentry;
+
+/* Plain-data mirror of Front + SparseMeta
+ * (GPUQREngine/Include/GPUQREngine_Front.hpp:20-86,
+ *  GPUQREngine/Include/GPUQREngine_SparseMeta.hpp:19-80).
+ * Field meaning is the reference's; fields the reference's scheduler kept for
+ * its own bookkeeping (state, lastSIndex, lastCiStart, ...) are absent. */
+typedef struct gpuqr_front
+{
+    int64_t fids;          /* front id within the batch; must equal the array index */
+    int64_t pids;          /* parent id within the batch, or -1 */
+    int64_t fidg, pidg;    /* global ids, carried through untouched */
+    int64_t fm, fn, fp;    /* rows, columns, pivotal columns */
+    int64_t rank;          /* rows of R pulled to cpuR: min(fm,fn) dense, min(fm,fp) sparse */
+    int32_t is_col_major;  /* dense overload only: layout of F and cpuR */
+    int32_t pad0;
+    int64_t ldn;           /* dense overload only: leading dimension of F and cpuR */
+    double *F;             /* dense overload: host input, fm-by-fn */
+    double *gpuF;          /* sparse overload: device front, row-major fm-by-fn, caller-zeroed */
+    double *cpuR;          /* host destination of R (and C if staged); NULL = leave on device */
+    const int64_t *Stair;  /* size fn, Stair[j] = last row of column j that may be nonzero; NULL = find it */
+
+    /* --- SparseMeta --- */
+    int32_t is_sparse;     /* 0: dense front, no assembly */
+    int32_t is_staged;     /* parent lives in a later stage: pull R and the cm rows of C */
+    int32_t push_only;     /* front is just a contribution block (cm-by-cn at gpuC, ld cn) to push */
+    int32_t nc;            /* number of children in this batch (informational) */
+    const gpuqr_sentry *gpuS; /* device S entries of this front */
+    int64_t Scount;
+    int32_t cm, cn;        /* contribution block is cm-by-cn */
+    int32_t pn;            /* columns of the parent front */
+    int32_t pad1;
+    const int32_t *gpuRjmap;  /* device, size cn: C column -> parent column */
+    const int32_t *gpuRimap;  /* device, size cm: C row -> parent row */
+    double *gpuC;          /* device location of C(0,0); its leading dimension is fn (cn if push_only) */
+} gpuqr_front;
+
+/* same fields as QREngineStats (GPUQREngine/Include/GPUQREngine_Stats.hpp:13-29) */
+typedef struct gpuqr_stats
+{
+    float   kernelTime;    /* ms spent in the round launches, measured with HIP events */
+    int64_t numLaunches;
+    int64_t flopsActual;
+} gpuqr_stats;
+
+/* Dense overload: replaces
+ *   QREngineResultCode GPUQREngine (size_t, Front *, Int, QREngineStats *)
+ * (GPUQREngine/Include/GPUQREngine.hpp:26-32,
+ *  GPUQREngine/Source/GPUQREngine_ExpertDense.cpp:29-158).
+ * Each front's F (host, row- or column-major with leading dimension ldn) is
+ * copied to the device, factorized, and the first `rank` rows of the reduced
+ * front are written to cpuR in the caller's layout. */
+int gpuqr_factor_dense (size_t gpuMemorySize, gpuqr_front *fronts, int64_t numFronts,
+                        gpuqr_stats *stats);
+
+/* Sparse overload: replaces
+ *   QREngineResultCode GPUQREngine (size_t, Front *, Int, Int *Parent, Int *Childp, Int *Child,
+ *                                   QREngineStats *)
+ * (GPUQREngine/Include/GPUQREngine.hpp:34-43,
+ *  GPUQREngine/Source/GPUQREngine_ExpertSparse.cpp:13-29, GPUQREngine_Internal.cpp:16-88).
+ * The caller owns every device buffer the fronts point to; the tree comes
+ * from pids.  Parent/Childp/Child are accepted and ignored, as in the
+ * reference.  Blocks until every front is reduced and its R (and C rows when
+ * is_staged) is in cpuR. */
+int gpuqr_factor_sparse (size_t gpuMemorySize, gpuqr_front *fronts, int64_t numFronts,
+                         const int64_t *Parent, const int64_t *Childp, const int64_t *Child,
+                         gpuqr_stats *stats);
+
+/* Replaces Int *GPUQREngine_FindStaircase (Front *)
+ * (GPUQREngine/Source/GPUQREngine_ExpertDense.cpp:196-217).  F is row-major
+ * fm-by-fn on the host.  Returns a malloc'd (through the hooks below) array of
+ * size fn, or NULL. */
+int64_t *gpuqr_find_staircase (const double *F, int64_t fm, int64_t fn);
+
+/* Replaces size_t ssgpu_maxQueueSize (size_t)
+ * (GPUQREngine/Source/Scheduler/ssgpu_maxQueueSize.cpp:6-27).  The value feeds
+ * the staging arithmetic only; the engine's own task list is not bounded by it. */
+size_t gpuqr_max_queue_size (size_t gpuMemorySize);
+
+/* Exact flop count of the schedule the engine would run for one fm-by-fn
+ * front with staircase Stair (NULL = full), the analogue of getFlops
+ * (GPUQREngine/Source/TaskDescriptor/TaskDescriptor_flops.cpp:70-104). */
+int64_t gpuqr_front_flops (int64_t fm, int64_t fn, const int64_t *Stair);
+
+/* Host allocator hooks, the analogue of SuiteSparse_config's function table
+ * (SuiteSparse_config/SuiteSparse_config.h:87-91): every host allocation the
+ * engine makes goes through these.  NULL restores malloc/calloc/free. */
+void gpuqr_set_allocator (void *(*malloc_fn) (size_t), void *(*calloc_fn) (size_t, size_t),
+                          void (*free_fn) (void *));
+
+/* Number of HIP devices visible, or 0 (never fails). */
+int gpuqr_device_count (void);
+
+/* Library version, major*1000 + minor */
+int gpuqr_version (void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

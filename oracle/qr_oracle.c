@@ -1,0 +1,322 @@
+/* CPU oracle for the multifrontal QR hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatement of the reference's algorithm, used as the checker by
+ * tests/, by __graft_entry__.smoke() and by bench.py's cpu_baseline leg.  The
+ * product (suitesparse_amd/) never links, loads or calls anything here.
+ *
+ * Pinning: the reference's device kernels need nvcc and its CPU SPQR needs a
+ * CUDA header, BLAS/LAPACK and METIS that are not part of the reference tree,
+ * so neither is built here.  The oracle is pinned against (1) the known-answer
+ * checks of the reference's own tests: ||triu(R)'triu(R) - A'A|| / ||A'A|| <=
+ * 1e-12 on the demo geometries with srand(1), rand()/1e8 entries
+ * (GPUQREngine/Demo/gpuqrengine_demo.cpp:21-28,94-112,283,305-308) and the
+ * qrtest bars ||R'R-(AP)'(AP)||_1/||A'A||_1 <= 1e-10, residual <= 1e-10
+ * (SPQR/Tcov/qrtest.cpp:1218-1257,2750-2763); (2) uniqueness of R up to row
+ * signs, checked against LAPACK (numpy) in tests/test_oracle.py; (3) the
+ * staging outcomes the survey recorded from the reference's own function.
+ * Integer outputs (staging, assembly maps, S scatter, pack assembly) are
+ * compared bit for bit with the product.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+typedef int64_t Long ;
+
+typedef struct { Long findex ; double value ; } oracle_sentry ;   /* GPUQREngine_SEntry.hpp:13-23 */
+
+/* ssgpu_maxQueueSize, GPUQREngine/Source/Scheduler/ssgpu_maxQueueSize.cpp:6-27 */
+size_t oracle_max_queue_size (size_t gpuMemorySize)
+{
+    size_t q ;
+    size_t tileSizeBytes = 32 * 32 * sizeof (double) ;
+    if (gpuMemorySize <= 1) q = 50000 ;
+    else q = 2 * (gpuMemorySize / tileSizeBytes) / 64 ;
+    if (q < 50000) q = 50000 ;
+    return q ;
+}
+
+/* GPUQREngine_FindStaircase, GPUQREngine/Source/GPUQREngine_ExpertDense.cpp:196-217 */
+void oracle_find_staircase (const double *F, Long fm, Long fn, Long *Stair)
+{
+    Long lastStair = 0 ;
+    for (Long j = 0 ; j < fn ; j++)
+    {
+        Long i ;
+        for (i = fm-1 ; i > lastStair && F [i*fn+j] == 0.0 ; i--) ;
+        Stair [j] = lastStair = i ;
+    }
+}
+
+/* Householder QR of one row-major front, column by column, with the device
+ * kernel's reflector convention (GPUQREngine/Include/Kernel/Factorize/
+ * factorize_vt.cu:272-293: sigma, s, v1, tau; z = -tau v'A, A += v z, :305-372)
+ * and the front semantics of the engine: every column k < min(fm,fn) consumes
+ * row k, the whole front is reduced (all fn columns), entries below the
+ * diagonal end up zero (factorize_vt.cu:492-496).  Stair (may be NULL) bounds
+ * the rows touched per column as in BucketList.cpp:107-128: rows above
+ * max(min(Stair[j],fm-1), j) inclusive. */
+void oracle_front_qr (double *F, Long fm, Long fn, const Long *Stair)
+{
+    Long kmax = (fm < fn) ? fm : fn ;
+    double *v = (double *) malloc ((size_t) (fm > 0 ? fm : 1) * sizeof (double)) ;
+    Long e = 0 ;
+    for (Long k = 0 ; k < kmax ; k++)
+    {
+        Long t = fm ;
+        if (Stair != NULL)
+        {
+            t = Stair [k] + 1 ;
+            if (t > fm) t = fm ;
+        }
+        if (t < k+1) t = k+1 ;
+        if (t < e) t = e ;          /* fill-in never shrinks the active rows */
+        e = t ;
+        double sigma = 0 ;
+        for (Long i = k+1 ; i < e ; i++) sigma += F [i*fn+k] * F [i*fn+k] ;
+        double x1 = F [k*fn+k] ;
+        double s, v1, tau ;
+        if (sigma <= 1e-90)
+        {
+            s = x1 ; v1 = 0 ; tau = 0 ;
+        }
+        else
+        {
+            s = sqrt (x1*x1 + sigma) ;
+            v1 = (x1 <= 0) ? (x1 - s) : (-sigma / (x1 + s)) ;
+            tau = -1 / (s * v1) ;
+        }
+        v [k] = v1 ;
+        for (Long i = k+1 ; i < e ; i++) v [i] = F [i*fn+k] ;
+        F [k*fn+k] = s ;
+        for (Long i = k+1 ; i < e ; i++) F [i*fn+k] = 0 ;
+        if (tau != 0)
+        {
+            for (Long j = k+1 ; j < fn ; j++)
+            {
+                double z = 0 ;
+                for (Long i = k ; i < e ; i++) z += v [i] * F [i*fn+j] ;
+                z *= -tau ;
+                for (Long i = k ; i < e ; i++) F [i*fn+j] += v [i] * z ;
+            }
+        }
+    }
+    free (v) ;
+}
+
+/* sassemble, GPUQREngine/Include/Kernel/Assemble/sAssemble.cu:5-19 */
+void oracle_sassemble (double *F, const oracle_sentry *S, Long pstart, Long pend)
+{
+    for (Long p = pstart ; p < pend ; p++) F [S [p].findex] = S [p].value ;
+}
+
+/* packassemble, GPUQREngine/Include/Kernel/Assemble/packAssemble.cu:39-56:
+ * P[pn*Rimap[ci] + Rjmap[cj]] = C[cld*ci + cj] for cj >= ci */
+void oracle_packassemble (const double *C, Long cld, Long cm, Long cn,
+    double *P, Long pn, const int *Rimap, const int *Rjmap)
+{
+    for (Long ci = 0 ; ci < cm ; ci++)
+        for (Long cj = ci ; cj < cn ; cj++)
+            P [pn * Rimap [ci] + Rjmap [cj]] = C [cld * ci + cj] ;
+}
+
+/* spqrgpu_buildAssemblyMaps, SPQR/SPQRGPU/spqrgpu_buildAssemblyMaps.cpp:8-190.
+ * Sj holds front-local column indices (spqr_analyze.cpp:869-880). */
+void oracle_build_assembly_maps
+(
+    Long nf, Long n, Long *Fmap, const Long *Post, const Long *Super, const Long *Rp, const Long *Rj,
+    const Long *Sleft, const Long *Sp, const Long *Sj, const double *Sx,
+    const Long *Fm, const Long *Cm, const Long *Childp, const Long *Child,
+    Long *CompleteStair, int *CompleteRjmap, const Long *RjmapOffsets,
+    int *CompleteRimap, const Long *RimapOffsets, oracle_sentry *cpuS
+)
+{
+    Long sindex = 0 ;
+    (void) n ; (void) Fm ;
+    for (Long pf = 0 ; pf < nf ; pf++)
+    {
+        Long f = Post [pf] ;
+        Long pstart = Rp [f], pend = Rp [f+1] ;
+        for (Long p = pstart ; p < pend ; p++) Fmap [Rj [p]] = p - pstart ;
+        Long *Stair = CompleteStair + Rp [f] ;
+        Long col1 = Super [f], col2 = Super [f+1] ;
+        Long fp = col2 - col1 ;
+        Long fn = Rp [f+1] - Rp [f] ;
+        for (Long j = 0 ; j < fp ; j++) Stair [j] = Sleft [j+col1+1] - Sleft [j+col1] ;
+        for (Long j = fp ; j < fn ; j++) Stair [j] = 0 ;
+        for (Long p = Childp [f] ; p < Childp [f+1] ; p++)
+        {
+            Long c = Child [p] ;
+            int *Rjmap = CompleteRjmap + RjmapOffsets [c] ;
+            Long pc = Rp [c] ;
+            Long fnc = Rp [c+1] - pc ;
+            Long fpc = Super [c+1] - Super [c] ;
+            Long cm = Cm [c] ;
+            Long cn = fnc - fpc ;
+            for (Long pp = 0 ; pp < cn ; pp++) Rjmap [pp] = (int) Fmap [Rj [pc+fpc+pp]] ;
+            pc += fpc ;
+            for (Long ci = 0 ; ci < cm ; ci++) Stair [Fmap [Rj [pc+ci]]]++ ;
+        }
+        Long fm = 0 ;
+        for (Long j = 0 ; j < fn ; j++)
+        {
+            Long t = fm ;
+            fm += Stair [j] ;
+            Stair [j] = t ;
+        }
+        Long Scount = Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]] ;
+        if (Scount > 0)
+        {
+            for (Long k = 0 ; k < fp ; k++)
+            {
+                Long leftcol = k + col1 ;
+                for (Long row = Sleft [leftcol] ; row < Sleft [leftcol+1] ; row++)
+                {
+                    Long i = Stair [k]++ ;
+                    for (Long p = Sp [row] ; p < Sp [row+1] ; p++)
+                    {
+                        cpuS [sindex].findex = i*fn + Sj [p] ;
+                        cpuS [sindex].value = Sx [p] ;
+                        sindex++ ;
+                    }
+                }
+            }
+        }
+        for (Long p = Childp [f] ; p < Childp [f+1] ; p++)
+        {
+            Long c = Child [p] ;
+            int *Rimap = CompleteRimap + RimapOffsets [c] ;
+            int *Rjmap = CompleteRjmap + RjmapOffsets [c] ;
+            Long cm = Cm [c] ;
+            for (Long ci = 0 ; ci < cm ; ci++)
+            {
+                Long j = Rjmap [ci] ;
+                Long i = Stair [j]++ ;
+                Rimap [ci] = (int) i ;
+            }
+        }
+    }
+}
+
+/* spqrgpu_computeFrontStaging, SPQR/SPQRGPU/spqrgpu_computeFrontStaging.cpp:75-249.
+ * sizeof(TaskDescriptor) = 104, TILESIZE = 32.  Returns 1 if feasible. */
+int oracle_compute_front_staging
+(
+    Long numFronts, const Long *Parent, const Long *Childp, const Long *Child,
+    const Long *Fm, const Long *Cm, const Long *Rp, const Long *Sp, const Long *Sleft,
+    const Long *Super, const Long *Post, Long RimapSize, Long RjmapSize, size_t gpuMemorySize,
+    Long *numStages, Long *Stagingp, Long *StageMap,
+    size_t *FSize, size_t *RSize, size_t *SSize, Long *FOffsets, Long *ROffsets, Long *SOffsets
+)
+{
+    (void) Parent ;
+    if (gpuMemorySize > 1)
+    {
+        size_t s = 2 * oracle_max_queue_size (gpuMemorySize) * 104 ;
+        gpuMemorySize = (gpuMemorySize > s) ? (gpuMemorySize - s) : 0 ;
+    }
+    if (gpuMemorySize > 1)
+    {
+        size_t s = RimapSize * sizeof (int) ;
+        gpuMemorySize = (gpuMemorySize > s) ? (gpuMemorySize - s) : 0 ;
+    }
+    if (gpuMemorySize > 1)
+    {
+        size_t s = RjmapSize * sizeof (int) ;
+        gpuMemorySize = (gpuMemorySize > s) ? (gpuMemorySize - s) : 0 ;
+    }
+    if (gpuMemorySize > 1)
+    {
+        size_t s = 1024 * 1024 ;
+        gpuMemorySize = (gpuMemorySize > s) ? (gpuMemorySize - s) : 0 ;
+    }
+    size_t ReqMem = 0, RMem = 0, SMem = 0, VTMem = 0 ;
+    Long stage = 0 ;
+    Stagingp [0] = 0 ;
+    for (Long p = 0 ; p < numFronts ; p++)
+    {
+        Long f = Post [p] ;
+        Long fm = Fm [f] ;
+        Long fn = Rp [f+1] - Rp [f] ;
+        Long fp = Super [f+1] - Super [f] ;
+        Long frank = (fm < fp) ? fm : fp ;
+        Long cm = Cm [f] ;
+        size_t frontMem = fm * fn ;
+        size_t rMem = (frank + cm) * fn ;
+        size_t sMem = 2 * (Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]]) ;
+        size_t vtMem = ((fm + 31) / 32) * 33 * 32 ;
+        size_t childMemOld = 0, childMemNew = 0 ;
+        for (Long cp = Childp [f] ; cp < Childp [f+1] ; cp++)
+        {
+            Long c = Child [cp] ;
+            Long ccn = (Rp [c+1] - Rp [c]) - (Super [c+1] - Super [c]) ;
+            Long ccm = Cm [c] ;
+            if (StageMap [c] < stage) childMemOld += ccm * ccn ;
+            else childMemNew += ccm * ccn ;
+        }
+        if ((ReqMem + (frontMem + childMemOld + sMem + vtMem)) * sizeof (double) < gpuMemorySize)
+        {
+            FOffsets [f] = ReqMem ; ROffsets [f] = RMem ; SOffsets [f] = SMem / 2 ;
+            ReqMem += frontMem + childMemOld ; RMem += rMem ; SMem += sMem ; VTMem += vtMem ;
+        }
+        else if (gpuMemorySize == 0 ||
+            ((frontMem + childMemOld + childMemNew + sMem + vtMem) * sizeof (double) < gpuMemorySize))
+        {
+            FSize [stage] = ReqMem ; RSize [stage] = RMem ; SSize [stage] = SMem / 2 ;
+            Stagingp [++stage] = p ;
+            ReqMem = 0 ; RMem = 0 ; SMem = 0 ; VTMem = 0 ;
+            FOffsets [f] = ReqMem ; ROffsets [f] = RMem ; SOffsets [f] = SMem / 2 ;
+            ReqMem += frontMem + childMemOld + childMemNew ; RMem += rMem ; SMem += sMem ; VTMem += vtMem ;
+        }
+        else
+        {
+            *numStages = 0 ;
+            return 0 ;
+        }
+        StageMap [f] = stage ;
+    }
+    FSize [stage] = ReqMem ; RSize [stage] = RMem ; SSize [stage] = SMem / 2 ;
+    Stagingp [++stage] = numFronts ;
+    if (Stagingp [stage] == Stagingp [stage-1]) stage-- ;
+    *numStages = stage ;
+    (void) VTMem ;
+    return 1 ;
+}
+
+/* Whole-tree numeric factorization on the CPU in the engine's data layout
+ * (row-major fronts, S scatter, pack assembly, front QR), all fronts in one
+ * stage: the differential twin of spqrgpu_kernel + GPUQREngine for one stage
+ * (SPQR/SPQRGPU/spqrgpu_kernel.cpp:486-555, Scheduler FSM
+ * GPUQREngine_FrontState.hpp:16-28).  Farena holds every front at FOffsets[f]
+ * and must be zero on entry; on return front f holds R in its first
+ * min(fm,fp) rows and C below. */
+void oracle_multifrontal
+(
+    Long nf, const Long *Post, const Long *Parent, const Long *Super, const Long *Rp,
+    const Long *Fm, const Long *Cm, const Long *Sleft, const Long *Sp,
+    const Long *Stair, const int *Rjmap, const Long *RjmapOffsets,
+    const int *Rimap, const Long *RimapOffsets, const oracle_sentry *cpuS,
+    const Long *FOffsets, const Long *SOffsets, double *Farena
+)
+{
+    for (Long k = 0 ; k < nf ; k++)
+    {
+        Long f = Post [k] ;
+        Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
+        double *F = Farena + FOffsets [f] ;
+        Long Scount = Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]] ;
+        if (Scount > 0) oracle_sassemble (F, cpuS + SOffsets [f], 0, Scount) ;
+        /* children were assembled into F when they finished (below) */
+        /* the engine treats Stair[j] as an inclusive row bound (BucketList.cpp:107-128) */
+        oracle_front_qr (F, fm, fn, Stair + Rp [f]) ;
+        Long pid = Parent [f] ;
+        if (pid >= 0 && pid < nf && Cm [f] > 0 && fn - fp > 0)
+        {
+            Long frank = (fm < fp) ? fm : fp ;
+            Long pn = Rp [pid+1] - Rp [pid] ;
+            oracle_packassemble (F + frank*fn + fp, fn, Cm [f], fn - fp,
+                Farena + FOffsets [pid], pn, Rimap + RimapOffsets [f], Rjmap + RjmapOffsets [f]) ;
+        }
+    }
+}

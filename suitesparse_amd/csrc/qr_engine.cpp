@@ -1,0 +1,654 @@
+// Host side of the front-batch QR engine: builds the complete task schedule
+// for a batch of fronts, uploads it once, replays it round by round on one HIP
+// stream, and pulls the R factors back while later rounds still run.
+//
+// Replaces the reference's host loop fillWorkQueue -> transferData ->
+// launchKernel -> postProcess (GPUQREngine/Source/GPUQREngine_Internal.cpp:57-73)
+// and the Scheduler / BucketList / LLBundle classes behind it
+// (GPUQREngine/Include/GPUQREngine_Scheduler.hpp:30-167,
+//  GPUQREngine_BucketList.hpp:25-166, GPUQREngine_LLBundle.hpp:27-94).
+//
+// Numerical method per front (fm x fn, row-major, staircase Stair): right-
+// looking blocked Householder QR with 32-column panels.  A panel's rows
+// [32p, e_p) are cut into chunks of 256 rows that are factorized
+// independently (level 0); the 32-row R factors on top of the chunks are then
+// merged 8 at a time (levels 1, 2, ...) until one R remains in the diagonal
+// block - a communication-avoiding (TSQR) panel, the generalisation of the
+// reference's bundles of three 32-row tiles (SURVEY of the tile schedule:
+// GPUQREngine/Source/BucketList/BucketList_CreateBundles.cpp:15-54,
+// LLBundle_Advance.cpp:19-80).  Every factorize task leaves a VT tile, and
+// apply tasks push its block reflector through the trailing columns, level by
+// level.  Round numbers encode the dependencies: a task of round r reads only
+// data produced in rounds < r.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <vector>
+#include <algorithm>
+#include <new>
+
+#include "qr_tasks.h"
+#include "../../include/gpuqrengine_amd.h"
+
+extern "C" int        qr_task_kernel_id (int type, int tier) ;
+extern "C" hipError_t qr_launch_tasks (int kid, const QrTask *d_tasks, int ntasks, hipStream_t stream) ;
+extern "C" hipError_t qr_kernels_init (void) ;
+
+#define QR_NKERNELS 9
+
+// -----------------------------------------------------------------------------
+// allocator hooks
+// -----------------------------------------------------------------------------
+
+static void *(*g_malloc) (size_t)         = malloc ;
+static void *(*g_calloc) (size_t, size_t) = calloc ;
+static void  (*g_free)   (void *)         = free ;
+
+extern "C" void gpuqr_set_allocator (void *(*m) (size_t), void *(*c) (size_t, size_t), void (*f) (void *))
+{
+    g_malloc = m ? m : malloc ;
+    g_calloc = c ? c : calloc ;
+    g_free   = f ? f : free ;
+}
+
+// std::vector storage that honours the hooks and reports failure by bad_alloc
+template <class T> struct HookAlloc
+{
+    typedef T value_type ;
+    HookAlloc ( ) { }
+    template <class U> HookAlloc (const HookAlloc<U> &) { }
+    T *allocate (size_t n)
+    {
+        if (n > (size_t) -1 / sizeof (T)) throw std::bad_alloc ( ) ;
+        void *p = g_malloc (n * sizeof (T)) ;
+        if (!p) throw std::bad_alloc ( ) ;
+        return (T *) p ;
+    }
+    void deallocate (T *p, size_t) { g_free (p) ; }
+    template <class U> bool operator== (const HookAlloc<U> &) const { return true ; }
+    template <class U> bool operator!= (const HookAlloc<U> &) const { return false ; }
+} ;
+template <class T> using hvec = std::vector<T, HookAlloc<T> > ;
+
+// -----------------------------------------------------------------------------
+// small entry points
+// -----------------------------------------------------------------------------
+
+extern "C" int gpuqr_version (void) { return 1000 ; }
+
+extern "C" int gpuqr_device_count (void)
+{
+    int n = 0 ;
+    if (hipGetDeviceCount (&n) != hipSuccess) return 0 ;
+    return n ;
+}
+
+extern "C" size_t gpuqr_max_queue_size (size_t gpuMemorySize)
+{
+    // ssgpu_maxQueueSize.cpp:6-27: two queue entries per 64 tiles of 32x32
+    // doubles of device memory, never fewer than 50000
+    const size_t min_queue = 50000 ;
+    const size_t tile_bytes = 32 * 32 * sizeof (double) ;
+    size_t q = min_queue ;
+    if (gpuMemorySize > 1) q = 2 * (gpuMemorySize / tile_bytes) / 64 ;
+    return (q < min_queue) ? min_queue : q ;
+}
+
+extern "C" int64_t *gpuqr_find_staircase (const double *F, int64_t fm, int64_t fn)
+{
+    // GPUQREngine_ExpertDense.cpp:196-217: Stair[j] is the last row of column
+    // j holding a nonzero, never above the previous column's stair
+    if (!F || fn < 0) return NULL ;
+    int64_t *Stair = (int64_t *) g_malloc ((size_t) (fn > 0 ? fn : 1) * sizeof (int64_t)) ;
+    if (!Stair) return NULL ;
+    int64_t last = 0 ;
+    for (int64_t j = 0 ; j < fn ; j++)
+    {
+        int64_t i = fm - 1 ;
+        while (i > last && F [i*fn + j] == 0.0) i-- ;
+        Stair [j] = last = i ;
+    }
+    return Stair ;
+}
+
+// -----------------------------------------------------------------------------
+// schedule
+// -----------------------------------------------------------------------------
+
+struct SchedTask
+{
+    QrTask  t ;
+    int32_t round ;
+    int64_t vt ;        // VT tile index or -1
+} ;
+
+struct Plan
+{
+    hvec<SchedTask> tasks ;
+    int64_t n_vt = 0 ;
+    int64_t flops = 0 ;
+    int32_t nrounds = 0 ;
+} ;
+
+static inline int tier_of (int K)
+{
+    return (K <= 32) ? 0 : (K <= 64) ? 1 : (K <= 128) ? 2 : 3 ;
+}
+
+static int64_t flops_factorize (int64_t K, int64_t w, bool with_t)
+{
+    int64_t fl = 0 ;
+    int64_t kmax = (K < w) ? K : w ;
+    for (int64_t k = 0 ; k < kmax ; k++)
+    {
+        int64_t h = K - k ;                     // length of the reflector
+        fl += 2*(h-1) + 6 ;                     // sum of squares, sqrt, scaling
+        fl += 4*h*(w-k-1) ;                     // v'A and the rank-1 update
+        if (with_t) fl += 2*h*k + k*k ;         // v_j'v_k and the T column
+    }
+    return fl ;
+}
+
+static inline int64_t flops_apply (int64_t K, int64_t w, int64_t n)
+{
+    // TaskDescriptor_flops.cpp:48-53 with m = K rows and k = w reflectors
+    return w * n * (4*K - w + 3) ;
+}
+
+struct Seg { int32_t row, n ; } ;
+
+// Emit all factorize/apply tasks of one front.  Returns the last round used.
+static int32_t plan_front
+(
+    Plan &plan, double *F, int64_t fm, int64_t fn, const int64_t *Stair,
+    int32_t start_round, bool emit
+)
+{
+    int32_t done = start_round - 1 ;
+    if (fm <= 0 || fn <= 0) return done ;
+    const int64_t mn = (fm < fn) ? fm : fn ;
+    const int64_t npanels = (mn + QR_PANEL_W - 1) / QR_PANEL_W ;
+    const int64_t ntiles  = (fn + QR_PANEL_W - 1) / QR_PANEL_W ;
+    hvec<int32_t> tileround ((size_t) ntiles, start_round - 1) ;
+    hvec<Seg> tops, next ;
+    hvec<int64_t> level_first, level_count ;      // index ranges into plan.tasks per level
+    int64_t e_prev = 0 ;
+
+    for (int64_t p = 0 ; p < npanels ; p++)
+    {
+        const int64_t c0 = p * QR_PANEL_W ;
+        const int64_t w = (fn - c0 < QR_PANEL_W) ? (fn - c0) : QR_PANEL_W ;
+        const int64_t r0 = c0 ;
+        int64_t e = fm ;
+        if (Stair != NULL)
+        {
+            e = Stair [c0 + w - 1] + 1 ;
+            if (e > fm) e = fm ;
+        }
+        int64_t emin = (r0 + w < fm) ? (r0 + w) : fm ;    // at least the diagonal block
+        if (e < emin) e = emin ;
+        if (e < e_prev) e = e_prev ;                      // fill from earlier panels
+        e_prev = e ;
+        const int64_t m = e - r0 ;
+        const bool trailing = (c0 + w < fn) ;
+
+        // ---- factorize tasks, level by level ---------------------------------
+        struct FRef { int64_t vt ; int32_t K ; int32_t nseg ; Seg segs [QR_MAX_SEG] ; int32_t level ; } ;
+        hvec<FRef> frefs ;
+        tops.clear ( ) ;
+        const int64_t nchunks = (m + QR_MAX_K - 1) / QR_MAX_K ;
+        int32_t level = 0 ;
+        const int32_t rF0 = tileround [p] + 1 ;
+        for (int64_t c = 0 ; c < nchunks ; c++)
+        {
+            FRef fr ;
+            int64_t a = r0 + c * QR_MAX_K ;
+            int64_t b = (a + QR_MAX_K < e) ? (a + QR_MAX_K) : e ;
+            fr.K = (int32_t) (b - a) ; fr.nseg = 1 ; fr.level = 0 ;
+            fr.segs [0].row = (int32_t) a ; fr.segs [0].n = fr.K ;
+            fr.vt = trailing ? plan.n_vt++ : -1 ;
+            frefs.push_back (fr) ;
+            Seg s ; s.row = (int32_t) a ; s.n = (int32_t) ((fr.K < w) ? fr.K : w) ;
+            tops.push_back (s) ;
+        }
+        while (tops.size ( ) > 1)
+        {
+            level++ ;
+            next.clear ( ) ;
+            for (size_t g = 0 ; g < tops.size ( ) ; g += QR_MAX_SEG)
+            {
+                size_t gend = std::min (g + (size_t) QR_MAX_SEG, tops.size ( )) ;
+                if (gend - g == 1) { next.push_back (tops [g]) ; continue ; }
+                FRef fr ; fr.nseg = (int32_t) (gend - g) ; fr.K = 0 ; fr.level = level ;
+                for (size_t s = g ; s < gend ; s++) { fr.segs [s-g] = tops [s] ; fr.K += tops [s].n ; }
+                fr.vt = trailing ? plan.n_vt++ : -1 ;
+                frefs.push_back (fr) ;
+                Seg s = tops [g] ; s.n = (int32_t) ((fr.K < w) ? fr.K : w) ;
+                next.push_back (s) ;
+            }
+            tops.swap (next) ;
+        }
+        const int32_t nlevels = level + 1 ;
+
+        for (size_t i = 0 ; i < frefs.size ( ) ; i++)
+        {
+            const FRef &fr = frefs [i] ;
+            plan.flops += flops_factorize (fr.K, w, trailing) ;
+            if (!emit) continue ;
+            SchedTask st ;
+            memset (&st, 0, sizeof (st)) ;
+            st.t.type = QR_TASK_FACTORIZE ;
+            st.t.tier = tier_of (fr.K) ;
+            QrPanelTask &pt = st.t.u.panel ;
+            pt.F = F ; pt.VT = NULL ; pt.ld = (int32_t) fn ; pt.col0 = (int32_t) c0 ; pt.w = (int32_t) w ;
+            pt.K = fr.K ; pt.nseg = fr.nseg ; pt.c_begin = pt.c_end = 0 ;
+            for (int s = 0 ; s < fr.nseg ; s++) { pt.seg_row [s] = fr.segs [s].row ; pt.seg_n [s] = fr.segs [s].n ; }
+            st.round = rF0 + fr.level ;
+            st.vt = fr.vt ;
+            plan.tasks.push_back (st) ;
+        }
+        done = std::max (done, rF0 + nlevels - 1) ;
+        tileround [p] = rF0 + nlevels - 1 ;
+
+        // ---- apply tasks ---------------------------------------------------------
+        if (trailing)
+        {
+            const int64_t t0 = p + 1 ;
+            int64_t bt = 4 ;                    // column tiles per apply task (128 columns)
+            while ((int64_t) frefs.size ( ) * ((ntiles - t0 + bt - 1) / bt) > 16384 && bt < 64) bt *= 2 ;
+            for (int32_t lv = 0 ; lv < nlevels ; lv++)
+            {
+                for (int64_t tb = t0 ; tb < ntiles ; tb += bt)
+                {
+                    const int64_t te = std::min (tb + bt, ntiles) ;
+                    int32_t ready = rF0 + lv ;
+                    for (int64_t t = tb ; t < te ; t++) ready = std::max (ready, tileround [t]) ;
+                    const int32_t round = ready + 1 ;
+                    const int64_t cb = tb * QR_PANEL_W ;
+                    const int64_t ce = std::min (te * QR_PANEL_W, fn) ;
+                    bool any = false ;
+                    for (size_t i = 0 ; i < frefs.size ( ) ; i++)
+                    {
+                        const FRef &fr = frefs [i] ;
+                        if (fr.level != lv) continue ;
+                        any = true ;
+                        plan.flops += flops_apply (fr.K, w, ce - cb) ;
+                        if (!emit) continue ;
+                        SchedTask st ;
+                        memset (&st, 0, sizeof (st)) ;
+                        st.t.type = QR_TASK_APPLY ;
+                        st.t.tier = tier_of (fr.K) ;
+                        QrPanelTask &pt = st.t.u.panel ;
+                        pt.F = F ; pt.VT = NULL ; pt.ld = (int32_t) fn ; pt.col0 = (int32_t) c0 ; pt.w = (int32_t) w ;
+                        pt.K = fr.K ; pt.nseg = fr.nseg ; pt.c_begin = (int32_t) cb ; pt.c_end = (int32_t) ce ;
+                        for (int s = 0 ; s < fr.nseg ; s++) { pt.seg_row [s] = fr.segs [s].row ; pt.seg_n [s] = fr.segs [s].n ; }
+                        st.round = round ;
+                        st.vt = fr.vt ;
+                        plan.tasks.push_back (st) ;
+                    }
+                    if (any)
+                    {
+                        for (int64_t t = tb ; t < te ; t++) tileround [t] = round ;
+                        done = std::max (done, round) ;
+                    }
+                }
+            }
+        }
+    }
+    return done ;
+}
+
+extern "C" int64_t gpuqr_front_flops (int64_t fm, int64_t fn, const int64_t *Stair)
+{
+    try
+    {
+        Plan plan ;
+        plan_front (plan, NULL, fm, fn, Stair, 1, false) ;
+        return plan.flops ;
+    }
+    catch (std::bad_alloc &) { return -1 ; }
+}
+
+// -----------------------------------------------------------------------------
+// the engine proper: fronts already on the device
+// -----------------------------------------------------------------------------
+
+#define HIP_TRY(call) do { hipError_t e_ = (call) ; if (e_ != hipSuccess) { \
+    if (getenv ("GPUQR_VERBOSE")) fprintf (stderr, "gpuqr: %s failed: %s (%s:%d)\n", #call, \
+        hipGetErrorString (e_), __FILE__, __LINE__) ; \
+    code = (e_ == hipErrorOutOfMemory) ? GPUQR_OUTOFMEMORY : GPUQR_GPUERROR ; goto cleanup ; } } while (0)
+
+static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
+{
+    int code = GPUQR_SUCCESS ;
+    QrTask *d_tasks = NULL ;
+    double *d_vt = NULL ;
+    hipStream_t sCompute = NULL, sCopy = NULL ;
+    hipEvent_t evStart = NULL, evStop = NULL ;
+    hvec<hipEvent_t> evRound ;
+    int64_t launches = 0 ;
+    float ms = 0 ;
+
+    if (stats) { stats->kernelTime = 0 ; stats->numLaunches = 0 ; stats->flopsActual = 0 ; }
+    if (nf <= 0) return GPUQR_SUCCESS ;
+
+    try
+    {
+        // ---- validate ---------------------------------------------------------------
+        for (int64_t f = 0 ; f < nf ; f++)
+        {
+            gpuqr_front &fr = fronts [f] ;
+            if (fr.fids != f) return GPUQR_GPUERROR ;
+            if (fr.pids < -1 || fr.pids >= nf || fr.pids == f) return GPUQR_GPUERROR ;
+            if (fr.fm < 0 || fr.fn < 0 || fr.fm > INT32_MAX || fr.fn > INT32_MAX) return GPUQR_GPUERROR ;
+            if (fr.fm > 0 && fr.fn > 0 && fr.gpuF == NULL) return GPUQR_GPUERROR ;
+            if (fr.is_sparse && fr.pids >= 0 && fr.cm > 0 && fr.cn > 0)
+            {
+                if (!fr.gpuRimap || !fr.gpuRjmap || !fr.gpuC) return GPUQR_GPUERROR ;
+                if (fronts [fr.pids].gpuF == NULL) return GPUQR_GPUERROR ;
+            }
+            if (fr.is_sparse && fr.Scount > 0 && !fr.gpuS) return GPUQR_GPUERROR ;
+        }
+
+        // ---- children-first order from pids -----------------------------------------
+        hvec<int64_t> nchild ((size_t) nf, 0), order ;
+        hvec<int32_t> child_pack_round ((size_t) nf, 0) ;   // max over children of their pack round
+        for (int64_t f = 0 ; f < nf ; f++) if (fronts [f].pids >= 0) nchild [fronts [f].pids]++ ;
+        order.reserve ((size_t) nf) ;
+        {
+            hvec<int64_t> pending (nchild) ;
+            hvec<int64_t> stack ;
+            for (int64_t f = 0 ; f < nf ; f++) if (pending [f] == 0) stack.push_back (f) ;
+            while (!stack.empty ( ))
+            {
+                int64_t f = stack.back ( ) ; stack.pop_back ( ) ;
+                order.push_back (f) ;
+                int64_t p = fronts [f].pids ;
+                if (p >= 0 && --pending [p] == 0) stack.push_back (p) ;
+            }
+            if ((int64_t) order.size ( ) != nf) return GPUQR_GPUERROR ;     // cycle in pids
+        }
+
+        // ---- build the schedule -----------------------------------------------------
+        Plan plan ;
+        hvec<int32_t> done_round ((size_t) nf, 0) ;
+        for (size_t k = 0 ; k < order.size ( ) ; k++)
+        {
+            const int64_t f = order [k] ;
+            gpuqr_front &fr = fronts [f] ;
+            int32_t done = 0 ;
+            if (!(fr.is_sparse && fr.push_only))
+            {
+                // S assembly, round 0
+                if (fr.is_sparse)
+                {
+                    for (int64_t ps = 0 ; ps < fr.Scount ; ps += QR_SASM_CHUNK)
+                    {
+                        SchedTask st ; memset (&st, 0, sizeof (st)) ;
+                        st.t.type = QR_TASK_SASSEMBLE ;
+                        st.t.u.sasm.F = fr.gpuF ; st.t.u.sasm.S = fr.gpuS ;
+                        st.t.u.sasm.pstart = ps ;
+                        st.t.u.sasm.pend = std::min (ps + (int64_t) QR_SASM_CHUNK, fr.Scount) ;
+                        st.round = 0 ; st.vt = -1 ;
+                        plan.tasks.push_back (st) ;
+                    }
+                }
+                int32_t start = std::max (1, child_pack_round [f] + 1) ;
+                done = plan_front (plan, fr.gpuF, fr.fm, fr.fn, fr.Stair, start, true) ;
+                if (done < start - 1) done = start - 1 ;
+            }
+            done_round [f] = done ;
+            // pack assembly into the parent
+            if (fr.is_sparse && fr.pids >= 0 && fr.cm > 0 && fr.cn > 0)
+            {
+                const int32_t round = done + 1 ;
+                const int32_t cld = fr.push_only ? fr.cn : (int32_t) fr.fn ;
+                for (int32_t ci = 0 ; ci < fr.cm ; ci += QR_PACK_TILE)
+                {
+                    for (int32_t cj = (ci / QR_PACK_TILE) * QR_PACK_TILE ; cj < fr.cn ; cj += QR_PACK_TILE)
+                    {
+                        SchedTask st ; memset (&st, 0, sizeof (st)) ;
+                        st.t.type = QR_TASK_PACKASSEMBLE ;
+                        QrPackAssembleTask &pk = st.t.u.pack ;
+                        pk.C = fr.gpuC ; pk.P = fronts [fr.pids].gpuF ;
+                        pk.Rjmap = fr.gpuRjmap ; pk.Rimap = fr.gpuRimap ;
+                        pk.cld = cld ; pk.pn = fr.pn ;
+                        pk.cistart = ci ; pk.ciend = std::min (ci + QR_PACK_TILE, fr.cm) ;
+                        pk.cjstart = cj ; pk.cjend = std::min (cj + QR_PACK_TILE, fr.cn) ;
+                        st.round = round ; st.vt = -1 ;
+                        plan.tasks.push_back (st) ;
+                    }
+                }
+                child_pack_round [fr.pids] = std::max (child_pack_round [fr.pids], round) ;
+                done_round [f] = round ;
+            }
+        }
+
+        const int64_t ntasks = (int64_t) plan.tasks.size ( ) ;
+        int32_t nrounds = 0 ;
+        for (int64_t i = 0 ; i < ntasks ; i++) nrounds = std::max (nrounds, plan.tasks [i].round + 1) ;
+
+        // counting sort by (round, kernel id): one launch per non-empty bucket
+        const int64_t nbuckets = (int64_t) nrounds * QR_NKERNELS ;
+        hvec<int64_t> rptr ((size_t) nbuckets + 1, 0) ;
+        for (int64_t i = 0 ; i < ntasks ; i++)
+        {
+            const SchedTask &st = plan.tasks [i] ;
+            rptr [(int64_t) st.round * QR_NKERNELS + qr_task_kernel_id (st.t.type, st.t.tier) + 1]++ ;
+        }
+        for (int64_t b = 0 ; b < nbuckets ; b++) rptr [b+1] += rptr [b] ;
+
+        if (hipStreamCreateWithFlags (&sCompute, hipStreamNonBlocking) != hipSuccess) { code = GPUQR_GPUERROR ; goto cleanup ; }
+        HIP_TRY (hipStreamCreateWithFlags (&sCopy, hipStreamNonBlocking)) ;
+        HIP_TRY (qr_kernels_init ( )) ;
+
+        if (ntasks > 0)
+        {
+            if (plan.n_vt > 0) HIP_TRY (hipMalloc ((void **) &d_vt, (size_t) plan.n_vt * QR_VT_DOUBLES * sizeof (double))) ;
+            hvec<QrTask> sorted ((size_t) ntasks) ;
+            {
+                hvec<int64_t> pos (rptr) ;
+                for (int64_t i = 0 ; i < ntasks ; i++)
+                {
+                    SchedTask &st = plan.tasks [i] ;
+                    if (st.t.type == QR_TASK_FACTORIZE || st.t.type == QR_TASK_APPLY)
+                    {
+                        QrPanelTask &pt = st.t.u.panel ;
+                        pt.VT = (st.vt >= 0) ? d_vt + (size_t) st.vt * QR_VT_DOUBLES : NULL ;
+                        // the kernels index LDS and registers by these bounds: check them here
+                        bool ok = pt.K >= 1 && pt.K <= QR_MAX_K && pt.w >= 1 && pt.w <= QR_PANEL_W
+                            && pt.nseg >= 1 && pt.nseg <= QR_MAX_SEG && pt.col0 >= 0 && pt.col0 + pt.w <= pt.ld
+                            && (st.t.type == QR_TASK_FACTORIZE || (pt.VT != NULL && pt.c_begin >= 0
+                                && pt.c_begin < pt.c_end && pt.c_end <= pt.ld)) ;
+                        int acc = 0 ;
+                        for (int s = 0 ; s < pt.nseg && ok ; s++) { ok = pt.seg_row [s] >= 0 && pt.seg_n [s] >= 1 ; acc += pt.seg_n [s] ; }
+                        if (!ok || acc != pt.K) { code = GPUQR_GPUERROR ; goto cleanup ; }
+                    }
+                    sorted [pos [(int64_t) st.round * QR_NKERNELS + qr_task_kernel_id (st.t.type, st.t.tier)]++] = st.t ;
+                }
+            }
+            HIP_TRY (hipMalloc ((void **) &d_tasks, (size_t) ntasks * sizeof (QrTask))) ;
+            HIP_TRY (hipMemcpyAsync (d_tasks, sorted.data ( ), (size_t) ntasks * sizeof (QrTask), hipMemcpyHostToDevice, sCompute)) ;
+            HIP_TRY (hipStreamSynchronize (sCompute)) ;      // 'sorted' may go out of scope below
+
+            // ---- fronts grouped by the round after which their data is final -------------
+            hvec<int64_t> pull_order ;
+            for (int64_t f = 0 ; f < nf ; f++)
+                if (fronts [f].cpuR != NULL && !(fronts [f].is_sparse && fronts [f].push_only)) pull_order.push_back (f) ;
+            std::sort (pull_order.begin ( ), pull_order.end ( ), [&] (int64_t a, int64_t b)
+                {
+                    int32_t ra = std::min (done_round [a], nrounds - 1), rb = std::min (done_round [b], nrounds - 1) ;
+                    return (ra != rb) ? (ra < rb) : (a < b) ;
+                }) ;
+
+            HIP_TRY (hipEventCreate (&evStart)) ;
+            HIP_TRY (hipEventCreate (&evStop)) ;
+            HIP_TRY (hipEventRecord (evStart, sCompute)) ;
+            size_t pi = 0 ;
+            for (int32_t r = 0 ; r < nrounds ; r++)
+            {
+                for (int kid = 0 ; kid < QR_NKERNELS ; kid++)
+                {
+                    const int64_t b = (int64_t) r * QR_NKERNELS + kid ;
+                    const int64_t n = rptr [b+1] - rptr [b] ;
+                    if (n > 0)
+                    {
+                        HIP_TRY (qr_launch_tasks (kid, d_tasks + rptr [b], (int) n, sCompute)) ;
+                        launches++ ;
+                    }
+                }
+                if (pi < pull_order.size ( ) && std::min (done_round [pull_order [pi]], nrounds - 1) <= r)
+                {
+                    hipEvent_t ev ;
+                    HIP_TRY (hipEventCreateWithFlags (&ev, hipEventDisableTiming)) ;
+                    evRound.push_back (ev) ;
+                    HIP_TRY (hipEventRecord (ev, sCompute)) ;
+                    HIP_TRY (hipStreamWaitEvent (sCopy, ev, 0)) ;
+                    while (pi < pull_order.size ( ) && std::min (done_round [pull_order [pi]], nrounds - 1) <= r)
+                    {
+                        gpuqr_front &fr = fronts [pull_order [pi++]] ;
+                        int64_t nvals = fr.rank * fr.fn ;
+                        if (fr.is_sparse && fr.is_staged) nvals += (int64_t) fr.cm * fr.fn ;
+                        if (nvals > fr.fm * fr.fn) nvals = fr.fm * fr.fn ;
+                        if (nvals > 0)
+                            HIP_TRY (hipMemcpyAsync (fr.cpuR, fr.gpuF, (size_t) nvals * sizeof (double), hipMemcpyDeviceToHost, sCopy)) ;
+                    }
+                }
+            }
+            HIP_TRY (hipEventRecord (evStop, sCompute)) ;
+            HIP_TRY (hipStreamSynchronize (sCompute)) ;
+            HIP_TRY (hipStreamSynchronize (sCopy)) ;
+            HIP_TRY (hipEventElapsedTime (&ms, evStart, evStop)) ;
+        }
+        if (stats)
+        {
+            stats->kernelTime = ms ;
+            stats->numLaunches = launches ;
+            stats->flopsActual = plan.flops ;
+        }
+    }
+    catch (std::bad_alloc &)
+    {
+        code = GPUQR_OUTOFMEMORY ;
+    }
+
+cleanup:
+    if (sCompute) (void) hipStreamSynchronize (sCompute) ;
+    if (sCopy) (void) hipStreamSynchronize (sCopy) ;
+    for (size_t i = 0 ; i < evRound.size ( ) ; i++) (void) hipEventDestroy (evRound [i]) ;
+    if (evStart) (void) hipEventDestroy (evStart) ;
+    if (evStop) (void) hipEventDestroy (evStop) ;
+    if (d_tasks) (void) hipFree (d_tasks) ;
+    if (d_vt) (void) hipFree (d_vt) ;
+    if (sCompute) (void) hipStreamDestroy (sCompute) ;
+    if (sCopy) (void) hipStreamDestroy (sCopy) ;
+    return code ;
+}
+
+extern "C" int gpuqr_factor_sparse
+(
+    size_t gpuMemorySize, gpuqr_front *fronts, int64_t numFronts,
+    const int64_t *Parent, const int64_t *Childp, const int64_t *Child, gpuqr_stats *stats
+)
+{
+    (void) gpuMemorySize ; (void) Parent ; (void) Childp ; (void) Child ;
+    if (numFronts < 0 || (numFronts > 0 && fronts == NULL)) return GPUQR_GPUERROR ;
+    return engine_run (fronts, numFronts, stats) ;
+}
+
+// -----------------------------------------------------------------------------
+// dense overload: host fronts in, R out
+// -----------------------------------------------------------------------------
+
+extern "C" int gpuqr_factor_dense
+(
+    size_t gpuMemorySize, gpuqr_front *userFronts, int64_t nf, gpuqr_stats *stats
+)
+{
+    (void) gpuMemorySize ;
+    int code = GPUQR_SUCCESS ;
+    if (stats) { stats->kernelTime = 0 ; stats->numLaunches = 0 ; stats->flopsActual = 0 ; }
+    if (nf < 0 || (nf > 0 && userFronts == NULL)) return GPUQR_GPUERROR ;
+    if (nf == 0) return GPUQR_SUCCESS ;
+
+    gpuqr_front *fronts = (gpuqr_front *) g_calloc ((size_t) nf, sizeof (gpuqr_front)) ;
+    int64_t **ownStair = (int64_t **) g_calloc ((size_t) nf, sizeof (int64_t *)) ;
+    double *hF = NULL, *hR = NULL, *dF = NULL ;
+    size_t FSize = 0, RSize = 0 ;
+    if (!fronts || !ownStair) { code = GPUQR_OUTOFMEMORY ; goto cleanup ; }
+
+    for (int64_t f = 0 ; f < nf ; f++)
+    {
+        gpuqr_front &u = userFronts [f] ;
+        if (u.fm < 0 || u.fn < 0 || (u.fm > 0 && u.fn > 0 && (!u.F || !u.cpuR))) { code = GPUQR_GPUERROR ; goto cleanup ; }
+        FSize += (size_t) u.fm * u.fn ;
+        RSize += (size_t) std::min (u.fm, u.fn) * u.fn ;
+    }
+    // pinned staging copies: the H2D/D2H transfers then run asynchronously
+    if (FSize > 0)
+    {
+        if (hipHostMalloc ((void **) &hF, FSize * sizeof (double), hipHostMallocDefault) != hipSuccess) { hF = NULL ; code = GPUQR_OUTOFMEMORY ; goto cleanup ; }
+        if (hipHostMalloc ((void **) &hR, std::max (RSize, (size_t) 1) * sizeof (double), hipHostMallocDefault) != hipSuccess) { hR = NULL ; code = GPUQR_OUTOFMEMORY ; goto cleanup ; }
+        if (hipMalloc ((void **) &dF, FSize * sizeof (double)) != hipSuccess) { dF = NULL ; code = GPUQR_OUTOFMEMORY ; goto cleanup ; }
+    }
+    {
+        size_t FOff = 0, ROff = 0 ;
+        for (int64_t f = 0 ; f < nf ; f++)
+        {
+            gpuqr_front &u = userFronts [f] ;
+            gpuqr_front &fr = fronts [f] ;
+            const int64_t m = u.fm, n = u.fn ;
+            const int64_t ldn = (u.ldn > 0) ? u.ldn : (u.is_col_major ? m : n) ;
+            fr.fids = f ; fr.pids = -1 ; fr.fidg = u.fidg ; fr.pidg = u.pidg ;
+            fr.fm = m ; fr.fn = n ; fr.fp = u.fp ; fr.rank = std::min (m, n) ;
+            fr.is_sparse = 0 ;
+            double *F = hF + FOff ;
+            fr.F = F ; fr.gpuF = dF + FOff ; fr.cpuR = hR + ROff ;
+            for (int64_t i = 0 ; i < m ; i++)
+                for (int64_t j = 0 ; j < n ; j++)
+                    F [i*n + j] = u.is_col_major ? u.F [j*ldn + i] : u.F [i*ldn + j] ;
+            fr.Stair = u.Stair ;
+            if (fr.Stair == NULL && m > 0 && n > 0)
+            {
+                ownStair [f] = gpuqr_find_staircase (F, m, n) ;
+                if (!ownStair [f]) { code = GPUQR_OUTOFMEMORY ; goto cleanup ; }
+                fr.Stair = ownStair [f] ;
+            }
+            FOff += (size_t) m * n ;
+            ROff += (size_t) fr.rank * n ;
+        }
+    }
+    if (FSize > 0 && hipMemcpy (dF, hF, FSize * sizeof (double), hipMemcpyHostToDevice) != hipSuccess) { code = GPUQR_GPUERROR ; goto cleanup ; }
+
+    code = engine_run (fronts, nf, stats) ;
+    if (code != GPUQR_SUCCESS) goto cleanup ;
+
+    for (int64_t f = 0 ; f < nf ; f++)
+    {
+        gpuqr_front &u = userFronts [f] ;
+        const int64_t m = u.fm, n = u.fn, rank = std::min (m, n) ;
+        const int64_t ldn = (u.ldn > 0) ? u.ldn : (u.is_col_major ? m : n) ;
+        const double *R = fronts [f].cpuR ;
+        u.rank = rank ;
+        // R(i,j), i < rank, goes to the caller's layout (the reference indexes the
+        // column-major case transposed, GPUQREngine_ExpertDense.cpp:146-152, which is
+        // only right for square R; here both layouts get the same matrix)
+        for (int64_t i = 0 ; i < rank ; i++)
+            for (int64_t j = 0 ; j < n ; j++)
+            {
+                if (u.is_col_major) u.cpuR [j*ldn + i] = R [i*n + j] ;
+                else                u.cpuR [i*ldn + j] = R [i*n + j] ;
+            }
+    }
+
+cleanup:
+    if (ownStair) { for (int64_t f = 0 ; f < nf ; f++) if (ownStair [f]) g_free (ownStair [f]) ; g_free (ownStair) ; }
+    if (fronts) g_free (fronts) ;
+    if (hF) (void) hipHostFree (hF) ;
+    if (hR) (void) hipHostFree (hR) ;
+    if (dF) (void) hipFree (dF) ;
+    return code ;
+}

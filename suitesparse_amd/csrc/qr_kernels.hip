@@ -1,0 +1,475 @@
+// HIP kernels (gfx950 / CDNA4) of the multifrontal QR engine.
+//
+// Every kernel runs one workgroup per task; all tasks of one launch belong to
+// the same round of the schedule.  Task kinds and what they replace in the
+// reference:
+//
+//   factorize_panel  panel Householder QR of up to 256 gathered rows x 32 cols
+//                    (GPUQREngine/Include/Kernel/Factorize/factorize_vt.cu:14-529,
+//                     which handles at most 96 rows as three 32-row tiles)
+//   apply_block      A <- A - V T' V' A on FP64 MFMA (v_mfma_f64_16x16x4_f64)
+//                    (GPUQREngine/Include/Kernel/Apply/block_apply.cu:270-550,
+//                     block_apply_chunk.cu:36-338)
+//   sassemble        F[findex] = value (Kernel/Assemble/sAssemble.cu:5-19)
+//   packassemble     child C -> parent front (Kernel/Assemble/packAssemble.cu:5-57)
+//
+// Fronts are row-major FP64, F(i,j) = F[i*fn + j], as in the reference
+// (factorize_vt.cu:101).  Wavefronts are 64 lanes; every workgroup has 256
+// threads = 4 waves, one per SIMD of a CU.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "qr_tasks.h"
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+#define HOUSE_EPS 1e-90     // same "column is already zero" threshold as factorize_vt.cu:12
+
+// -----------------------------------------------------------------------------
+// local row -> front row map of a panel task (in LDS)
+// -----------------------------------------------------------------------------
+
+__device__ __forceinline__ void build_rowmap (const QrPanelTask &t, int *rowmap, int cap)
+{
+    for (int r = threadIdx.x ; r < cap ; r += QR_THREADS)
+    {
+        int g = -1, acc = 0 ;
+        for (int s = 0 ; s < t.nseg ; s++)
+        {
+            int n = t.seg_n [s] ;
+            if (g < 0 && r < acc + n) g = t.seg_row [s] + (r - acc) ;
+            acc += n ;
+        }
+        rowmap [r] = g ;
+    }
+}
+
+// -----------------------------------------------------------------------------
+// factorize_panel
+// -----------------------------------------------------------------------------
+//
+// Thread (rg, c), rg = tid/32 in 0..7, c = tid%32, keeps rows rg, rg+8, ... of
+// column c in registers (RPT of them).  Per column k: the two lanes per wave
+// that own column k publish it to LDS with their partial sum of squares, every
+// thread forms the normalised Householder vector v (v_k = 1), computes its
+// share of v'A, the 8 row groups are reduced with one cross-half shuffle and a
+// 4-entry LDS sum, and the rank-1 update is applied in registers.  Two
+// barriers per column.  Columns j < k hold v_j, so the same dot products give
+// -tau_k v_j'v_k, from which T is built (T(0:k-1,k) = T(0:k-1,0:k-1) z(0:k-1),
+// the recurrence of factorize_vt.cu:397-410 and spqr_larftb.cpp:13-22).
+//
+// Householder convention (restated from factorize_vt.cu:272-293, but with v
+// scaled to a unit head so that V1 fits the strictly-lower part of the VT
+// tile):  sigma = sum_{i>k} a_ik^2;  if sigma <= 1e-90: tau = 0, R_kk = a_kk;
+// else s = sqrt(a_kk^2 + sigma), v1 = a_kk - s (a_kk <= 0) or -sigma/(a_kk+s),
+// R_kk = s >= 0, v = [1; a_{k+1:,k}/v1], tau = -v1/s.
+
+struct FactorizeLds
+{
+    int    rowmap [QR_MAX_K] ;
+    double vbuf   [2][QR_MAX_K] ;
+    double sig    [8] ;
+    double x1 ;
+    double dpart  [4][32] ;
+    double Z      [32][33] ;
+    double T      [32][33] ;
+    double tau    [32] ;
+} ;
+
+template <int RPT>
+__device__ void factorize_panel (const QrPanelTask &t, char *smem)
+{
+    FactorizeLds &L = *reinterpret_cast<FactorizeLds *>(smem) ;
+    const int tid = threadIdx.x ;
+    const int c = tid & 31 ;
+    const int rg = tid >> 5 ;
+    const int wave = tid >> 6 ;
+    const int K = t.K, w = t.w, ld = t.ld ;
+    const int kmax = (K < w) ? K : w ;
+    double *F = t.F ;
+
+    build_rowmap (t, L.rowmap, 8*RPT) ;
+    for (int i = tid ; i < 32*33 ; i += QR_THREADS) { (&L.Z[0][0]) [i] = 0 ; (&L.T[0][0]) [i] = 0 ; }
+    __syncthreads ( ) ;
+
+    double a [RPT] ;
+    #pragma unroll
+    for (int i = 0 ; i < RPT ; i++)
+    {
+        int r = rg + 8*i ;
+        a [i] = (r < K && c < w) ? F [(size_t) L.rowmap [r] * ld + t.col0 + c] : 0.0 ;
+    }
+
+    for (int k = 0 ; k < kmax ; k++)
+    {
+        double *vb = L.vbuf [k & 1] ;    // double buffered: stragglers still read the other one
+        if (c == k)
+        {
+            double part = 0 ;
+            #pragma unroll
+            for (int i = 0 ; i < RPT ; i++)
+            {
+                int r = rg + 8*i ;
+                double x = a [i] ;
+                if (r > k) { part += x*x ; vb [r] = x ; }
+                else if (r == k) { L.x1 = x ; }
+            }
+            L.sig [rg] = part ;
+        }
+        __syncthreads ( ) ;
+
+        double sigma = ((L.sig [0] + L.sig [1]) + (L.sig [2] + L.sig [3]))
+                     + ((L.sig [4] + L.sig [5]) + (L.sig [6] + L.sig [7])) ;
+        double x1 = L.x1 ;
+        double s, tau, inv ;
+        if (sigma <= HOUSE_EPS)
+        {
+            s = x1 ; tau = 0 ; inv = 0 ;
+        }
+        else
+        {
+            s = sqrt (x1*x1 + sigma) ;
+            double v1 = (x1 <= 0) ? (x1 - s) : (-sigma / (x1 + s)) ;
+            tau = -v1 / s ;
+            inv = 1.0 / v1 ;
+        }
+
+        double d = 0 ;
+        #pragma unroll
+        for (int i = 0 ; i < RPT ; i++)
+        {
+            int r = rg + 8*i ;
+            double vr = (r > k && r < K) ? vb [r] * inv : ((r == k) ? 1.0 : 0.0) ;
+            d += vr * a [i] ;
+        }
+        d += __shfl_xor (d, 32) ;
+        if ((tid & 63) < 32) L.dpart [wave][c] = d ;
+        __syncthreads ( ) ;
+
+        double z = -tau * ((L.dpart [0][c] + L.dpart [1][c]) + (L.dpart [2][c] + L.dpart [3][c])) ;
+        if (c > k)
+        {
+            #pragma unroll
+            for (int i = 0 ; i < RPT ; i++)
+            {
+                int r = rg + 8*i ;
+                double vr = (r > k && r < K) ? vb [r] * inv : ((r == k) ? 1.0 : 0.0) ;
+                a [i] += vr * z ;
+            }
+        }
+        else if (c == k)
+        {
+            #pragma unroll
+            for (int i = 0 ; i < RPT ; i++)
+            {
+                int r = rg + 8*i ;
+                if (r == k) a [i] = s ; else if (r > k) a [i] = (r < K) ? vb [r] * inv : 0.0 ;
+            }
+        }
+        else if (rg == 0)
+        {
+            L.Z [c][k] = z ;
+        }
+        if (tid == 0) L.tau [k] = tau ;
+    }
+
+    // ---- T (only when somebody will apply this panel) ------------------------
+    if (t.VT != NULL)
+    {
+        __syncthreads ( ) ;
+        if (tid < 32)
+        {
+            // lane j builds row j of T, column by column; it only ever reads
+            // entries of its own row (written by itself) and Z
+            for (int k = 0 ; k < kmax ; k++)
+            {
+                if (tid < k)
+                {
+                    double acc = 0 ;
+                    for (int i = tid ; i < k ; i++) acc += L.T [tid][i] * L.Z [i][k] ;
+                    L.T [tid][k] = acc ;
+                }
+                else if (tid == k)
+                {
+                    L.T [k][k] = L.tau [k] ;
+                }
+            }
+        }
+        __syncthreads ( ) ;
+    }
+
+    // ---- write back -----------------------------------------------------------
+    #pragma unroll
+    for (int i = 0 ; i < RPT ; i++)
+    {
+        int r = rg + 8*i ;
+        if (r < K && c < w)
+        {
+            size_t p = (size_t) L.rowmap [r] * ld + t.col0 + c ;
+            if (r < w)
+            {
+                F [p] = (c >= r) ? a [i] : 0.0 ;
+                if (t.VT != NULL) t.VT [r*32 + c] = (c < r) ? a [i] : L.T [r][c] ;
+            }
+            else
+            {
+                F [p] = a [i] ;
+            }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------
+// apply_block
+// -----------------------------------------------------------------------------
+//
+// V (K x 32, unit lower trapezoidal) and T (32 x 32 upper) are staged once in
+// LDS.  Each of the 4 waves then walks 16-column slabs of [c_begin,c_end).  A
+// slab (K x 16) lives in registers as MT = K/16 MFMA C/D tiles.  For
+// v_mfma_f64_16x16x4_f64 the C/D tile register i of lane l is element
+// (row 4i + l/16, col l%16), which is exactly the B-operand layout of the
+// 4-row slice 4i..4i+3, so the same registers serve as
+//   B operand of  W  = V' A      (32 x 16, contraction over the K rows)
+//   accumulator of A -= V (T' W) (contraction over the 32 reflector columns)
+// and the slab makes one trip from HBM and back with no LDS staging of A.
+// LDS row stride 34 doubles keeps the A-operand reads of step 3 conflict free.
+
+#define VS_LD 34
+
+template <int MT>
+__device__ void apply_block (const QrPanelTask &t, char *smem)
+{
+    double (*Vs)[VS_LD] = reinterpret_cast<double (*)[VS_LD]>(smem) ;                       // [MT*16][34]
+    double (*Ts)[VS_LD] = reinterpret_cast<double (*)[VS_LD]>(smem + (size_t) MT*16*VS_LD*8) ; // [32][34]
+    int *rowmap = reinterpret_cast<int *>(smem + (size_t) (MT*16 + 32)*VS_LD*8) ;            // [MT*16]
+
+    const int tid = threadIdx.x ;
+    const int K = t.K, w = t.w, ld = t.ld ;
+    const int kmax = (K < w) ? K : w ;
+    double *F = t.F ;
+    const double *VT = t.VT ;
+
+    build_rowmap (t, rowmap, MT*16) ;
+    __syncthreads ( ) ;
+
+    for (int idx = tid ; idx < MT*16*32 ; idx += QR_THREADS)
+    {
+        int r = idx >> 5, c = idx & 31 ;
+        double val = 0 ;
+        if (r < K && c < kmax)
+        {
+            if (r < w) val = (c < r) ? VT [r*32 + c] : ((c == r) ? 1.0 : 0.0) ;
+            else       val = F [(size_t) rowmap [r] * ld + t.col0 + c] ;
+        }
+        Vs [r][c] = val ;
+    }
+    for (int idx = tid ; idx < 32*32 ; idx += QR_THREADS)
+    {
+        int r = idx >> 5, c = idx & 31 ;
+        Ts [r][c] = (c >= r && c < kmax) ? VT [r*32 + c] : 0.0 ;
+    }
+    __syncthreads ( ) ;
+
+    const int lane = tid & 63, wave = tid >> 6 ;
+    const int lr = lane >> 4, lc = lane & 15 ;
+    const int nslab = (t.c_end - t.c_begin + 15) >> 4 ;
+
+    for (int slab = wave ; slab < nslab ; slab += 4)
+    {
+        const int col = t.c_begin + slab*16 + lc ;
+        const bool cvalid = col < t.c_end ;
+
+        v4f64 A [MT] ;
+        #pragma unroll
+        for (int mt = 0 ; mt < MT ; mt++)
+        {
+            #pragma unroll
+            for (int i = 0 ; i < 4 ; i++)
+            {
+                int r = mt*16 + 4*i + lr ;
+                A [mt][i] = (cvalid && r < K) ? F [(size_t) rowmap [r] * ld + col] : 0.0 ;
+            }
+        }
+
+        // step 1: W = V' A, two 16-row tiles of W, two accumulators each
+        v4f64 W0a = {0,0,0,0}, W1a = {0,0,0,0}, W0b = {0,0,0,0}, W1b = {0,0,0,0} ;
+        #pragma unroll
+        for (int mt = 0 ; mt < MT ; mt++)
+        {
+            #pragma unroll
+            for (int i = 0 ; i < 4 ; i++)
+            {
+                int r = mt*16 + 4*i + lr ;
+                double b = A [mt][i] ;
+                if (i & 1)
+                {
+                    W0b = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [r][lc],      b, W0b, 0, 0, 0) ;
+                    W1b = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [r][16 + lc], b, W1b, 0, 0, 0) ;
+                }
+                else
+                {
+                    W0a = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [r][lc],      b, W0a, 0, 0, 0) ;
+                    W1a = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [r][16 + lc], b, W1a, 0, 0, 0) ;
+                }
+            }
+        }
+        v4f64 W0 = W0a + W0b, W1 = W1a + W1b ;
+
+        // step 2: X = T' W (T upper triangular: rows 16..31 of T do not reach X0)
+        v4f64 X0 = {0,0,0,0}, X1 = {0,0,0,0} ;
+        #pragma unroll
+        for (int q = 0 ; q < 4 ; q++)
+        {
+            X0 = __builtin_amdgcn_mfma_f64_16x16x4f64 (Ts [4*q + lr][lc],      W0 [q], X0, 0, 0, 0) ;
+            X1 = __builtin_amdgcn_mfma_f64_16x16x4f64 (Ts [4*q + lr][16 + lc], W0 [q], X1, 0, 0, 0) ;
+        }
+        #pragma unroll
+        for (int q = 0 ; q < 4 ; q++)
+        {
+            X1 = __builtin_amdgcn_mfma_f64_16x16x4f64 (Ts [16 + 4*q + lr][16 + lc], W1 [q], X1, 0, 0, 0) ;
+        }
+        X0 = -X0 ; X1 = -X1 ;
+
+        // step 3: A += V (-X)
+        #pragma unroll
+        for (int mt = 0 ; mt < MT ; mt++)
+        {
+            v4f64 acc = A [mt] ;
+            #pragma unroll
+            for (int q = 0 ; q < 4 ; q++)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [mt*16 + lc][4*q + lr], X0 [q], acc, 0, 0, 0) ;
+            #pragma unroll
+            for (int q = 0 ; q < 4 ; q++)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [mt*16 + lc][16 + 4*q + lr], X1 [q], acc, 0, 0, 0) ;
+            A [mt] = acc ;
+        }
+
+        // Recompute the store addresses from the row map instead of keeping
+        // 64 address pairs alive across the MFMA section: the opaque copy of
+        // the lane row stops the compiler from reusing the load addresses.
+        int lr_st = lr ;
+        asm volatile ("" : "+v" (lr_st)) ;
+        #pragma unroll
+        for (int mt = 0 ; mt < MT ; mt++)
+        {
+            #pragma unroll
+            for (int i = 0 ; i < 4 ; i++)
+            {
+                int r = mt*16 + 4*i + lr_st ;
+                if (cvalid && r < K) F [(size_t) rowmap [r] * ld + col] = A [mt][i] ;
+            }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------
+// assembly
+// -----------------------------------------------------------------------------
+
+struct SEntryDev { long long findex ; double value ; } ;    // 16 bytes, GPUQREngine_SEntry.hpp:13-23
+
+__device__ void sassemble (const QrSAssembleTask &t)
+{
+    const SEntryDev *S = reinterpret_cast<const SEntryDev *>(t.S) ;
+    double *F = t.F ;
+    for (int64_t p = t.pstart + threadIdx.x ; p < t.pend ; p += QR_THREADS)
+    {
+        SEntryDev e = S [p] ;
+        F [e.findex] = e.value ;
+    }
+}
+
+__device__ void packassemble (const QrPackAssembleTask &t, char *smem)
+{
+    int *shRimap = reinterpret_cast<int *>(smem) ;          // [QR_PACK_TILE]
+    int *shRjmap = shRimap + QR_PACK_TILE ;                 // [QR_PACK_TILE]
+    const int ctm = t.ciend - t.cistart ;
+    const int ctn = t.cjend - t.cjstart ;
+    for (int p = threadIdx.x ; p < ctm ; p += QR_THREADS) shRimap [p] = t.Rimap [t.cistart + p] ;
+    for (int p = threadIdx.x ; p < ctn ; p += QR_THREADS) shRjmap [p] = t.Rjmap [t.cjstart + p] ;
+    __syncthreads ( ) ;
+    // one wave per row of the tile, lanes along the (contiguous) child columns;
+    // only the upper trapezoid cj >= ci carries data (packAssemble.cu:47-55)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6 ;
+    for (int cil = wave ; cil < ctm ; cil += 4)
+    {
+        const int ci = t.cistart + cil ;
+        const double *Crow = t.C + (size_t) ci * t.cld ;
+        double *Prow = t.P + (size_t) shRimap [cil] * t.pn ;
+        for (int cjl = lane ; cjl < ctn ; cjl += 64)
+        {
+            int cj = t.cjstart + cjl ;
+            if (cj >= ci) Prow [shRjmap [cjl]] = Crow [cj] ;
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------
+// kernels: one per task kind and row tier, so each gets its own register budget
+// -----------------------------------------------------------------------------
+
+template <int RPT>
+__global__ void __launch_bounds__ (QR_THREADS) k_factorize (const QrTask *tasks)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem [] ;
+    factorize_panel<RPT> (tasks [blockIdx.x].u.panel, smem) ;
+}
+
+template <int MT>
+__global__ void __launch_bounds__ (QR_THREADS, 2) k_apply (const QrTask *tasks)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem [] ;
+    apply_block<MT> (tasks [blockIdx.x].u.panel, smem) ;
+}
+
+__global__ void __launch_bounds__ (QR_THREADS) k_assemble (const QrTask *tasks)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem [] ;
+    const QrTask &t = tasks [blockIdx.x] ;
+    if (t.type == QR_TASK_SASSEMBLE) sassemble (t.u.sasm) ;
+    else                             packassemble (t.u.pack, smem) ;
+}
+
+// Kernel id of a task: 0..3 factorize tiers, 4..7 apply tiers, 8 assembly.
+extern "C" int qr_task_kernel_id (int type, int tier)
+{
+    if (type == QR_TASK_FACTORIZE) return tier ;
+    if (type == QR_TASK_APPLY)     return 4 + tier ;
+    return 8 ;
+}
+
+static size_t kernel_lds_bytes (int kid)
+{
+    if (kid < 4) return sizeof (FactorizeLds) ;
+    if (kid < 8) { size_t rows = (size_t) 32 << (kid - 4) ; return (rows + 32) * VS_LD * 8 + rows * 4 ; }
+    return 2 * QR_PACK_TILE * sizeof (int) ;
+}
+
+// Launch ntasks consecutive tasks, all of kernel id kid, one workgroup each.
+extern "C" hipError_t qr_launch_tasks (int kid, const QrTask *d_tasks, int ntasks, hipStream_t stream)
+{
+    if (ntasks <= 0) return hipSuccess ;
+    const dim3 grid (ntasks), block (QR_THREADS) ;
+    const size_t lds = kernel_lds_bytes (kid) ;
+    switch (kid)
+    {
+        case 0: hipLaunchKernelGGL (k_factorize<4>,  grid, block, lds, stream, d_tasks) ; break ;
+        case 1: hipLaunchKernelGGL (k_factorize<8>,  grid, block, lds, stream, d_tasks) ; break ;
+        case 2: hipLaunchKernelGGL (k_factorize<16>, grid, block, lds, stream, d_tasks) ; break ;
+        case 3: hipLaunchKernelGGL (k_factorize<32>, grid, block, lds, stream, d_tasks) ; break ;
+        case 4: hipLaunchKernelGGL (k_apply<2>,      grid, block, lds, stream, d_tasks) ; break ;
+        case 5: hipLaunchKernelGGL (k_apply<4>,      grid, block, lds, stream, d_tasks) ; break ;
+        case 6: hipLaunchKernelGGL (k_apply<8>,      grid, block, lds, stream, d_tasks) ; break ;
+        case 7: hipLaunchKernelGGL (k_apply<16>,     grid, block, lds, stream, d_tasks) ; break ;
+        case 8: hipLaunchKernelGGL (k_assemble,      grid, block, lds, stream, d_tasks) ; break ;
+        default: return hipErrorInvalidValue ;
+    }
+    return hipGetLastError ( ) ;
+}
+
+extern "C" hipError_t qr_kernels_init (void)
+{
+    // dynamic LDS above 64 KB needs an explicit opt-in on HIP
+    return hipFuncSetAttribute ((const void *) k_apply<16>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int) kernel_lds_bytes (7)) ;
+}
