@@ -72,9 +72,99 @@ struct FactorizeLds
     double x1 ;
     double dpart  [4][32] ;
     double Z      [32][33] ;
-    double T      [32][33] ;
     double tau    [32] ;
 } ;
+
+// The 8 Householder steps k = 8*IK .. 8*IK+7.  With rows dealt to threads as
+// r = rg + 8*i, the register slot of the pivot row (i = IK) is a compile-time
+// constant inside this function: slots i < IK lie entirely above the pivot row
+// and are skipped, slots i > IK lie entirely below it and need no masks; only
+// slot IK is compared against the runtime row group of the pivot.
+template <int RPT, int IK>
+__device__ __forceinline__ void house_steps
+(
+    double (&a) [RPT], FactorizeLds &L, const int kmax, const int rg, const int c, const int tid
+)
+{
+    if constexpr (IK < RPT)
+    {
+        const int wave = tid >> 6 ;
+        double v [RPT] ;
+        for (int rgk = 0 ; rgk < 8 ; rgk++)
+        {
+            const int k = 8*IK + rgk ;
+            if (k >= kmax) break ;
+            double *vb = L.vbuf [k & 1] ;    // double buffered: stragglers still read the other one
+
+            // ---- owners of column k publish it and their share of sigma ----------
+            if (c == k)
+            {
+                double part = 0 ;
+                #pragma unroll
+                for (int i = IK ; i < RPT ; i++)
+                {
+                    const double x = a [i] ;
+                    if (i > IK || rg > rgk) { part += x*x ; vb [rg + 8*i] = x ; }
+                    else if (rg == rgk) { L.x1 = x ; }
+                }
+                L.sig [rg] = part ;
+            }
+            __syncthreads ( ) ;
+
+            const double sigma = ((L.sig [0] + L.sig [1]) + (L.sig [2] + L.sig [3]))
+                               + ((L.sig [4] + L.sig [5]) + (L.sig [6] + L.sig [7])) ;
+            const double x1 = L.x1 ;
+            double s, tau, inv ;
+            if (sigma <= HOUSE_EPS)
+            {
+                s = x1 ; tau = 0 ; inv = 0 ;
+            }
+            else
+            {
+                s = sqrt (x1*x1 + sigma) ;
+                const double v1 = (x1 <= 0) ? (x1 - s) : (-sigma / (x1 + s)) ;
+                tau = -v1 / s ;
+                inv = 1.0 / v1 ;
+            }
+
+            // ---- v'A over rows >= k ------------------------------------------------
+            double d = 0 ;
+            #pragma unroll
+            for (int i = IK ; i < RPT ; i++)
+            {
+                double vr ;
+                if (i > IK) vr = vb [rg + 8*i] * inv ;
+                else        vr = (rg > rgk) ? vb [rg + 8*i] * inv : ((rg == rgk) ? 1.0 : 0.0) ;
+                v [i] = vr ;
+                d += vr * a [i] ;
+            }
+            d += __shfl_xor (d, 32) ;
+            if ((tid & 63) < 32) L.dpart [wave][c] = d ;
+            __syncthreads ( ) ;
+
+            const double z = -tau * ((L.dpart [0][c] + L.dpart [1][c]) + (L.dpart [2][c] + L.dpart [3][c])) ;
+            if (c > k)
+            {
+                #pragma unroll
+                for (int i = IK ; i < RPT ; i++) a [i] += v [i] * z ;
+            }
+            else if (c == k)
+            {
+                #pragma unroll
+                for (int i = IK ; i < RPT ; i++)
+                {
+                    if (i > IK || rg > rgk) a [i] = v [i] ;
+                    else if (rg == rgk)     a [i] = s ;
+                }
+            }
+            else if (rg == 0)
+            {
+                L.Z [c][k] = z ;
+            }
+            if (tid == 0) L.tau [k] = tau ;
+        }
+    }
+}
 
 template <int RPT>
 __device__ void factorize_panel (const QrPanelTask &t, char *smem)
@@ -83,13 +173,13 @@ __device__ void factorize_panel (const QrPanelTask &t, char *smem)
     const int tid = threadIdx.x ;
     const int c = tid & 31 ;
     const int rg = tid >> 5 ;
-    const int wave = tid >> 6 ;
     const int K = t.K, w = t.w, ld = t.ld ;
     const int kmax = (K < w) ? K : w ;
     double *F = t.F ;
+    double *VT = t.VT ;
 
     build_rowmap (t, L.rowmap, 8*RPT) ;
-    for (int i = tid ; i < 32*33 ; i += QR_THREADS) { (&L.Z[0][0]) [i] = 0 ; (&L.T[0][0]) [i] = 0 ; }
+    for (int i = tid ; i < 32*33 ; i += QR_THREADS) (&L.Z[0][0]) [i] = 0 ;
     __syncthreads ( ) ;
 
     double a [RPT] ;
@@ -100,105 +190,12 @@ __device__ void factorize_panel (const QrPanelTask &t, char *smem)
         a [i] = (r < K && c < w) ? F [(size_t) L.rowmap [r] * ld + t.col0 + c] : 0.0 ;
     }
 
-    for (int k = 0 ; k < kmax ; k++)
-    {
-        double *vb = L.vbuf [k & 1] ;    // double buffered: stragglers still read the other one
-        if (c == k)
-        {
-            double part = 0 ;
-            #pragma unroll
-            for (int i = 0 ; i < RPT ; i++)
-            {
-                int r = rg + 8*i ;
-                double x = a [i] ;
-                if (r > k) { part += x*x ; vb [r] = x ; }
-                else if (r == k) { L.x1 = x ; }
-            }
-            L.sig [rg] = part ;
-        }
-        __syncthreads ( ) ;
+    house_steps<RPT, 0> (a, L, kmax, rg, c, tid) ;
+    house_steps<RPT, 1> (a, L, kmax, rg, c, tid) ;
+    house_steps<RPT, 2> (a, L, kmax, rg, c, tid) ;
+    house_steps<RPT, 3> (a, L, kmax, rg, c, tid) ;
 
-        double sigma = ((L.sig [0] + L.sig [1]) + (L.sig [2] + L.sig [3]))
-                     + ((L.sig [4] + L.sig [5]) + (L.sig [6] + L.sig [7])) ;
-        double x1 = L.x1 ;
-        double s, tau, inv ;
-        if (sigma <= HOUSE_EPS)
-        {
-            s = x1 ; tau = 0 ; inv = 0 ;
-        }
-        else
-        {
-            s = sqrt (x1*x1 + sigma) ;
-            double v1 = (x1 <= 0) ? (x1 - s) : (-sigma / (x1 + s)) ;
-            tau = -v1 / s ;
-            inv = 1.0 / v1 ;
-        }
-
-        double d = 0 ;
-        #pragma unroll
-        for (int i = 0 ; i < RPT ; i++)
-        {
-            int r = rg + 8*i ;
-            double vr = (r > k && r < K) ? vb [r] * inv : ((r == k) ? 1.0 : 0.0) ;
-            d += vr * a [i] ;
-        }
-        d += __shfl_xor (d, 32) ;
-        if ((tid & 63) < 32) L.dpart [wave][c] = d ;
-        __syncthreads ( ) ;
-
-        double z = -tau * ((L.dpart [0][c] + L.dpart [1][c]) + (L.dpart [2][c] + L.dpart [3][c])) ;
-        if (c > k)
-        {
-            #pragma unroll
-            for (int i = 0 ; i < RPT ; i++)
-            {
-                int r = rg + 8*i ;
-                double vr = (r > k && r < K) ? vb [r] * inv : ((r == k) ? 1.0 : 0.0) ;
-                a [i] += vr * z ;
-            }
-        }
-        else if (c == k)
-        {
-            #pragma unroll
-            for (int i = 0 ; i < RPT ; i++)
-            {
-                int r = rg + 8*i ;
-                if (r == k) a [i] = s ; else if (r > k) a [i] = (r < K) ? vb [r] * inv : 0.0 ;
-            }
-        }
-        else if (rg == 0)
-        {
-            L.Z [c][k] = z ;
-        }
-        if (tid == 0) L.tau [k] = tau ;
-    }
-
-    // ---- T (only when somebody will apply this panel) ------------------------
-    if (t.VT != NULL)
-    {
-        __syncthreads ( ) ;
-        if (tid < 32)
-        {
-            // lane j builds row j of T, column by column; it only ever reads
-            // entries of its own row (written by itself) and Z
-            for (int k = 0 ; k < kmax ; k++)
-            {
-                if (tid < k)
-                {
-                    double acc = 0 ;
-                    for (int i = tid ; i < k ; i++) acc += L.T [tid][i] * L.Z [i][k] ;
-                    L.T [tid][k] = acc ;
-                }
-                else if (tid == k)
-                {
-                    L.T [k][k] = L.tau [k] ;
-                }
-            }
-        }
-        __syncthreads ( ) ;
-    }
-
-    // ---- write back -----------------------------------------------------------
+    // ---- write back R (zeros below the diagonal), V2 in place, V1 to the VT tile ----
     #pragma unroll
     for (int i = 0 ; i < RPT ; i++)
     {
@@ -209,12 +206,45 @@ __device__ void factorize_panel (const QrPanelTask &t, char *smem)
             if (r < w)
             {
                 F [p] = (c >= r) ? a [i] : 0.0 ;
-                if (t.VT != NULL) t.VT [r*32 + c] = (c < r) ? a [i] : L.T [r][c] ;
+                if (VT != NULL && c < r) VT [r*32 + c] = a [i] ;
             }
             else
             {
                 F [p] = a [i] ;
             }
+        }
+    }
+
+    // ---- T (only when somebody will apply this panel) ------------------------
+    if (VT != NULL)
+    {
+        __syncthreads ( ) ;
+        if (tid < 32)
+        {
+            // lane j owns row j of T in registers; T(j,i) = 0 for i < j, so the
+            // unmasked sum below is the triangular product T(0:k-1,0:k-1) z
+            double trow [32] ;
+            #pragma unroll
+            for (int i = 0 ; i < 32 ; i++) trow [i] = 0 ;
+            #pragma unroll
+            for (int k = 0 ; k < 32 ; k++)
+            {
+                if (k < kmax)
+                {
+                    double acc0 = 0, acc1 = 0 ;
+                    #pragma unroll
+                    for (int i = 0 ; i + 1 < k ; i += 2)
+                    {
+                        acc0 += trow [i]   * L.Z [i][k] ;
+                        acc1 += trow [i+1] * L.Z [i+1][k] ;
+                    }
+                    if (k & 1) acc0 += trow [k-1] * L.Z [k-1][k] ;
+                    trow [k] = (tid < k) ? (acc0 + acc1) : ((tid == k) ? L.tau [k] : 0.0) ;
+                }
+            }
+            #pragma unroll
+            for (int i = 0 ; i < 32 ; i++)
+                if (i >= tid && tid < w && i < w) VT [tid*32 + i] = trow [i] ;
         }
     }
 }
