@@ -1,0 +1,120 @@
+/* C ABI of the SPQR <-> engine glue on MI355X: staging, assembly maps, the
+ * per-stage numeric driver, and the small symbolic front end that lets the
+ * library run stand-alone on a box without SuiteSparse.
+ *
+ * Int = int64_t everywhere (SuiteSparse_long, SPQR's Long).
+ */
+#ifndef SPQRGPU_AMD_H
+#define SPQRGPU_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "gpuqrengine_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Replaces void spqrgpu_computeFrontStaging (...)
+ * (SPQR/Include/spqrgpu.hpp:16-57, SPQR/SPQRGPU/spqrgpu_computeFrontStaging.cpp:31-249).
+ * Same arguments in the same order, with cc->gpuMemorySize passed by value
+ * and the return value replacing *feasible (1 feasible, 0 not; on 0
+ * *numStages = 0 and the caller raises CHOLMOD_GPU_PROBLEM).  The arithmetic
+ * is bit-for-bit the reference's, including sizeof(TaskDescriptor) = 104. */
+int spqrgpu_amd_compute_front_staging
+(
+    int64_t numFronts, const int64_t *Parent, const int64_t *Childp, const int64_t *Child,
+    const int64_t *Fm, const int64_t *Cm, const int64_t *Rp, const int64_t *Sp, const int64_t *Sleft,
+    const int64_t *Super, const int64_t *Post, int64_t RimapSize, int64_t RjmapSize,
+    size_t gpuMemorySize,
+    int64_t *numStages, int64_t *Stagingp, int64_t *StageMap,
+    size_t *FSize, size_t *RSize, size_t *SSize,
+    int64_t *FOffsets, int64_t *ROffsets, int64_t *SOffsets
+);
+
+/* Replaces void spqrgpu_buildAssemblyMaps (...)
+ * (SPQR/Include/spqrgpu.hpp:59-82, SPQR/SPQRGPU/spqrgpu_buildAssemblyMaps.cpp:8-190). */
+void spqrgpu_amd_build_assembly_maps
+(
+    int64_t numFronts, int64_t n, int64_t *Fmap, const int64_t *Post, const int64_t *Super,
+    const int64_t *Rp, const int64_t *Rj, const int64_t *Sleft, const int64_t *Sp, const int64_t *Sj,
+    const double *Sx, const int64_t *Fm, const int64_t *Cm, const int64_t *Childp, const int64_t *Child,
+    int64_t *CompleteStair, int32_t *CompleteRjmap, const int64_t *RjmapOffsets,
+    int32_t *CompleteRimap, const int64_t *RimapOffsets, gpuqr_sentry *cpuS
+);
+
+/* Replaces numfronts_in_stage (SPQR/SPQRGPU/spqrgpu_kernel.cpp:26-56): number of
+ * children of this stage's fronts that were factorized in an earlier stage. */
+int64_t spqrgpu_amd_numfronts_in_stage
+(
+    int64_t stage, const int64_t *Stagingp, const int64_t *StageMap, const int64_t *Post,
+    const int64_t *Child, const int64_t *Childp
+);
+
+/* --- symbolic object ------------------------------------------------------- */
+
+/* Opaque mirror of the parts of spqr_symbolic + spqr_gpu the GPU path reads
+ * (SPQR/Include/SuiteSparseQR.hpp:118-260). */
+typedef struct spqr_amd_symbolic spqr_amd_symbolic;
+
+/* Stand-alone symbolic analysis of A(:,Q) for the GPU path: column elimination
+ * tree, postorder, fundamental supernodes (optionally relaxed), front patterns
+ * Rp/Rj, S = A(P,Q) in row form with front-local column indices, Fm, Cm, map
+ * offsets, canonical flop count, and the staging for gpuMemorySize.  It stands
+ * in for spqr_analyze (SPQR/Source/spqr_analyze.cpp:75-1130) on a machine
+ * without CHOLMOD; an SPQR build passes its own QRsym arrays to the functions
+ * above instead.  A is m-by-n in compressed-column form, Quser a column
+ * permutation or NULL.  *status: 0 ok, 1 out of memory, 2 staging infeasible,
+ * 3 invalid input. */
+spqr_amd_symbolic *spqr_amd_analyze
+(
+    int64_t m, int64_t n, const int64_t *Ap, const int64_t *Ai, const int64_t *Quser,
+    int relax, size_t gpuMemorySize, int *status
+);
+
+void spqr_amd_symbolic_free (spqr_amd_symbolic *sym);
+
+/* Named access: arrays "Qfill" "PLinv" "Sleft" "Sp" "Sj" "Super" "Rp" "Rj" "Parent" "Childp" "Child"
+ * "Post" "Fm" "Cm" "RjmapOffsets" "RimapOffsets" "Stagingp" "StageMap" "FSize" "RSize" "SSize"
+ * "FOffsets" "ROffsets" "SOffsets" "ColCount"; returns NULL for an unknown name. */
+const int64_t *spqr_amd_symbolic_array (const spqr_amd_symbolic *sym, const char *name, int64_t *len);
+/* scalars "m" "n" "anz" "nf" "maxfn" "rjsize" "RimapSize" "RjmapSize" "numStages" "flopcount" "rnz";
+ * returns -1 for an unknown name. */
+double spqr_amd_symbolic_scalar (const spqr_amd_symbolic *sym, const char *name);
+
+/* --- numeric driver -------------------------------------------------------- */
+
+typedef struct spqr_amd_numeric
+{
+    int64_t  nf;
+    int64_t  rsize;         /* doubles in Rstack */
+    double  *Rstack;        /* all R blocks, column-packed upper trapezoidal, as on SPQR's stack */
+    int64_t *Rblock;        /* size nf: offset of front f's block in Rstack */
+    char    *Rdead;         /* size n: 1 for pivot columns past the bottom of their front */
+    int64_t  sumfrank, maxfrank;
+    double   gpuKernelTime; /* ms */
+    int64_t  gpuFlops, gpuNumKernelLaunches;
+    int64_t  numStagesRun;
+    double   assembleBytes; /* algorithmic bytes moved by S- and pack-assembly */
+} spqr_amd_numeric;
+
+/* Replaces void spqrgpu_kernel (spqr_blob <double> *Blob)
+ * (SPQR/Include/spqrgpu.hpp:9-14, SPQR/SPQRGPU/spqrgpu_kernel.cpp:63-782): stage
+ * loop, Front construction, limbo contribution blocks, engine call, R packed
+ * onto a stack.  Ax are the values of A in the same compressed-column order
+ * given to spqr_amd_analyze.  Returns 0, or 1 out of memory, 2 GPU problem. */
+int spqrgpu_amd_factorize (const spqr_amd_symbolic *sym, const int64_t *Ap, const int64_t *Ai,
+                           const double *Ax, spqr_amd_numeric **num_out);
+
+void spqr_amd_numeric_free (spqr_amd_numeric *num);
+
+/* R as an n-column compressed-column matrix (rows = sumfrank), the job of
+ * spqr_rcount + spqr_rconvert (SPQR/Source/spqr_rconvert.cpp).  First call
+ * with Rp only (size n+1) to get the counts, then with Ri/Rx of size Rp[n]. */
+int spqr_amd_rconvert (const spqr_amd_symbolic *sym, const spqr_amd_numeric *num,
+                       int64_t *Rp, int64_t *Ri, double *Rx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

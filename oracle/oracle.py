@@ -53,3 +53,91 @@ def front_qr(F, Stair=None):
     st = None if Stair is None else np.ascontiguousarray(Stair, dtype=np.int64)
     lib().oracle_front_qr(_p(A), C.c_int64(fm), C.c_int64(fn), None if st is None else _p(st))
     return A
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def compute_front_staging(nf, Parent, Childp, Child, Fm, Cm, Rp, Sp, Sleft, Super, Post,
+                          RimapSize, RjmapSize, gpuMemorySize):
+    """oracle_compute_front_staging; same result dict as suitesparse_amd.spqr.spqrgpu_computeFrontStaging."""
+    a = [_i64(x) for x in (Parent, Childp, Child, Fm, Cm, Rp, Sp, Sleft, Super, Post)]
+    numStages = C.c_int64(0)
+    Stagingp = np.zeros(nf + 2, np.int64)
+    StageMap = np.zeros(nf + 1, np.int64)
+    FSize, RSize, SSize = (np.zeros(nf + 1, np.uint64) for _ in range(3))
+    FOff, ROff, SOff = (np.zeros(nf + 1, np.int64) for _ in range(3))
+    f = lib().oracle_compute_front_staging
+    f.restype = C.c_int
+    f.argtypes = [C.c_int64] + [C.c_void_p] * 10 + [C.c_int64, C.c_int64, C.c_size_t,
+                                                    C.POINTER(C.c_int64)] + [C.c_void_p] * 8
+    ok = f(nf, *[_p(x) for x in a], RimapSize, RjmapSize, gpuMemorySize, C.byref(numStages),
+           _p(Stagingp), _p(StageMap), _p(FSize), _p(RSize), _p(SSize), _p(FOff), _p(ROff), _p(SOff))
+    return dict(feasible=bool(ok), numStages=int(numStages.value), Stagingp=Stagingp, StageMap=StageMap,
+                FSize=FSize, RSize=RSize, SSize=SSize, FOffsets=FOff, ROffsets=ROff, SOffsets=SOff)
+
+
+def build_assembly_maps(sym, Sx):
+    """oracle_build_assembly_maps on the arrays of a symbolic object (any object with the
+    SPQR field names); returns (Stair, Rjmap, Rimap, cpuS)."""
+    nf, n = sym.nf, sym.n
+    Fmap = np.zeros(max(n, 1), np.int64)
+    Stair = np.zeros(max(int(sym.Rp[nf]), 1), np.int64)
+    Rjmap = np.zeros(max(sym.RjmapSize, 1), np.int32)
+    Rimap = np.zeros(max(sym.RimapSize, 1), np.int32)
+    cpuS = np.zeros(max(sym.anz, 1), dtype=np.dtype([("findex", np.int64), ("value", np.float64)]))
+    Sx = np.ascontiguousarray(Sx, dtype=np.float64)
+    f = lib().oracle_build_assembly_maps
+    f.restype = None
+    f.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 19
+    f(nf, n, _p(Fmap), _p(_i64(sym.Post)), _p(_i64(sym.Super)), _p(_i64(sym.Rp)), _p(_i64(sym.Rj)),
+      _p(_i64(sym.Sleft)), _p(_i64(sym.Sp)), _p(_i64(sym.Sj)), _p(Sx), _p(_i64(sym.Fm)), _p(_i64(sym.Cm)),
+      _p(_i64(sym.Childp)), _p(_i64(sym.Child)), _p(Stair), _p(Rjmap), _p(_i64(sym.RjmapOffsets)),
+      _p(Rimap), _p(_i64(sym.RimapOffsets)), _p(cpuS))
+    return Stair, Rjmap, Rimap, cpuS
+
+
+def multifrontal(sym, Sx):
+    """CPU multifrontal QR over the whole tree in the engine's layout (one stage).
+    Returns (Farena, FOffsets): front f, reduced, is Farena[FOffsets[f]:][:fm*fn] row-major."""
+    nf = sym.nf
+    Stair, Rjmap, Rimap, cpuS = build_assembly_maps(sym, Sx)
+    fn = np.diff(_i64(sym.Rp))[:nf]
+    sizes = _i64(sym.Fm)[:nf] * fn
+    FOff = np.zeros(nf + 1, np.int64)
+    FOff[1:] = np.cumsum(sizes)
+    # S entries are packed front after front in postorder
+    Scount = np.array([sym.Sp[sym.Sleft[sym.Super[f + 1]]] - sym.Sp[sym.Sleft[sym.Super[f]]] for f in range(nf)],
+                      dtype=np.int64)
+    SOff = np.zeros(nf + 1, np.int64)
+    post = _i64(sym.Post)[:nf]
+    SOff[post] = np.concatenate([[0], np.cumsum(Scount[post])[:-1]]) if nf > 0 else 0
+    Farena = np.zeros(max(int(FOff[nf]), 1))
+    f = lib().oracle_multifrontal
+    f.restype = None
+    f.argtypes = [C.c_int64] + [C.c_void_p] * 17
+    f(nf, _p(post), _p(_i64(sym.Parent)), _p(_i64(sym.Super)), _p(_i64(sym.Rp)), _p(_i64(sym.Fm)),
+      _p(_i64(sym.Cm)), _p(_i64(sym.Sleft)), _p(_i64(sym.Sp)), _p(Stair), _p(Rjmap),
+      _p(_i64(sym.RjmapOffsets)), _p(Rimap), _p(_i64(sym.RimapOffsets)), _p(cpuS), _p(FOff), _p(SOff),
+      _p(Farena))
+    return Farena, FOff
+
+
+def r_from_fronts(sym, Farena, FOff):
+    """Assemble the dense n-column R (rows = sum of front ranks) from reduced fronts."""
+    nf, n = sym.nf, sym.n
+    rows = int(sum(min(int(sym.Fm[f]), int(sym.Super[f + 1] - sym.Super[f])) for f in range(nf)))
+    R = np.zeros((rows, n))
+    row1 = 0
+    for f in range(nf):
+        fm = int(sym.Fm[f])
+        fp = int(sym.Super[f + 1] - sym.Super[f])
+        cols = _i64(sym.Rj)[sym.Rp[f]:sym.Rp[f + 1]]
+        fnn = cols.size
+        F = Farena[FOff[f]:FOff[f] + fm * fnn].reshape(fm, fnn)
+        rk = min(fm, fp)
+        for i in range(rk):
+            R[row1 + i, cols[i:]] = F[i, i:]
+        row1 += rk
+    return R

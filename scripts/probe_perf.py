@@ -33,6 +33,10 @@ def run(shapes, reps=3):
           f"canon {flops/w/1e9:8.1f} GF/s (kernel-only {flops/k/1e9:8.1f})  actual/canon {fa/flops:.2f}", flush=True)
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        m, n, cnt = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+        run([(m, n)]*cnt, reps=int(sys.argv[4]) if len(sys.argv) > 4 else 3)
+        sys.exit(0)
     run([(96, 32)]*4096)
     run([(384, 128)]*1024)
     run([(1536, 512)]*64)

@@ -1,0 +1,420 @@
+// Stand-alone symbolic front end for the GPU QR path.
+//
+// On a machine with SuiteSparse the arrays below come from spqr_analyze
+// (SPQR/Source/spqr_analyze.cpp:75-1130, which obtains the supernodes from
+// CHOLMOD).  This file produces the same arrays - same names, same meaning,
+// same conventions (placeholder front nf, Parent[nf] = -1, Sleft of size n+2,
+// front-local Sj, Fm/Cm without rank detection) - from A and a column
+// permutation alone, so that the numeric GPU path can run and be tested where
+// only this repository exists.  The supernode partition is the fundamental one
+// (optionally relaxed by merging a front into its parent when that adds few
+// explicit zeros); it is not CHOLMOD's, so front counts differ from an SPQR run
+// on the same matrix while every array stays self-consistent.
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+#include <new>
+
+#include "../../include/spqrgpu_amd.h"
+#include "spqr_symbolic.h"
+
+typedef int64_t Long ;
+
+// -----------------------------------------------------------------------------
+// column elimination tree of A(:,Q) (the etree of (AQ)'(AQ)), Liu's algorithm
+// with path compression, run on the rows' "previous column" links
+// -----------------------------------------------------------------------------
+
+static void column_etree (Long m, Long n, const Long *Ap, const Long *Ai, const Long *Q, Long *parent)
+{
+    std::vector<Long> anc (n, -1), prev (m, -1) ;
+    for (Long k = 0 ; k < n ; k++)
+    {
+        parent [k] = -1 ;
+        const Long col = Q ? Q [k] : k ;
+        for (Long p = Ap [col] ; p < Ap [col+1] ; p++)
+        {
+            const Long row = Ai [p] ;
+            Long i = prev [row] ;
+            while (i != -1 && i < k)
+            {
+                Long next = anc [i] ;
+                anc [i] = k ;
+                if (next == -1) parent [i] = k ;
+                i = next ;
+            }
+            prev [row] = k ;
+        }
+    }
+}
+
+// postorder of a forest given by parent[]; children visited in increasing order
+static void tree_postorder (Long n, const Long *parent, Long *post)
+{
+    std::vector<Long> head (n, -1), next (n, -1), stack ;
+    for (Long j = n-1 ; j >= 0 ; j--)
+    {
+        if (parent [j] != -1) { next [j] = head [parent [j]] ; head [parent [j]] = j ; }
+    }
+    Long k = 0 ;
+    for (Long root = 0 ; root < n ; root++)
+    {
+        if (parent [root] != -1) continue ;
+        stack.push_back (root) ;
+        while (!stack.empty ( ))
+        {
+            Long j = stack.back ( ) ;
+            Long c = head [j] ;
+            if (c == -1) { post [k++] = j ; stack.pop_back ( ) ; }
+            else { head [j] = next [c] ; stack.push_back (c) ; }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------
+// the analysis
+// -----------------------------------------------------------------------------
+
+extern "C" spqr_amd_symbolic *spqr_amd_analyze
+(
+    int64_t m, int64_t n, const int64_t *Ap, const int64_t *Ai, const int64_t *Quser,
+    int relax, size_t gpuMemorySize, int *status
+)
+{
+    int dummy ;
+    if (!status) status = &dummy ;
+    *status = 0 ;
+    if (m < 0 || n < 0 || !Ap || (Ap [n] > 0 && !Ai)) { *status = 3 ; return NULL ; }
+    spqr_amd_symbolic *S = NULL ;
+    try
+    {
+        S = new spqr_amd_symbolic ( ) ;
+        S->m = m ; S->n = n ; S->anz = Ap [n] ;
+        const Long anz = Ap [n] ;
+
+        // ---- etree of A(:,Quser), postorder, composed permutation ----------------------
+        std::vector<Long> parent0 (n), post (n) ;
+        column_etree (m, n, Ap, Ai, Quser, parent0.data ( )) ;
+        tree_postorder (n, parent0.data ( ), post.data ( )) ;
+        std::vector<Long> ipost (n), parent (n) ;
+        for (Long k = 0 ; k < n ; k++) ipost [post [k]] = k ;
+        S->Qfill.resize (n) ;
+        for (Long k = 0 ; k < n ; k++)
+        {
+            S->Qfill [k] = Quser ? Quser [post [k]] : post [k] ;
+            Long p = parent0 [post [k]] ;
+            parent [k] = (p == -1) ? -1 : ipost [p] ;
+        }
+        std::vector<Long> Qinv (n) ;
+        for (Long k = 0 ; k < n ; k++) Qinv [S->Qfill [k]] = k ;
+
+        // ---- S = A(P,Q) in row form, rows sorted by leftmost column -------------------
+        // (spqr_stranspose1: SPQR/Source/spqr_stranspose1.cpp)
+        std::vector<Long> leftmost (m, n), rowcount (m, 0) ;
+        for (Long k = 0 ; k < n ; k++)
+        {
+            const Long col = S->Qfill [k] ;
+            for (Long p = Ap [col] ; p < Ap [col+1] ; p++)
+            {
+                const Long i = Ai [p] ;
+                if (i < 0 || i >= m) { *status = 3 ; delete S ; return NULL ; }
+                if (leftmost [i] == n) leftmost [i] = k ;
+                rowcount [i]++ ;
+            }
+        }
+        S->Sleft.assign (n+2, 0) ;
+        // Sleft[k] = first row of S whose leftmost column is k; Sleft[n] = # nonempty rows,
+        // Sleft[n+1] = m (empty rows of A go last)
+        for (Long i = 0 ; i < m ; i++) S->Sleft [leftmost [i] + 1]++ ;
+        for (Long k = 0 ; k <= n ; k++) S->Sleft [k+1] += S->Sleft [k] ;
+        S->PLinv.resize (m) ;
+        {
+            std::vector<Long> nextrow (S->Sleft.begin ( ), S->Sleft.begin ( ) + n + 1) ;
+            for (Long i = 0 ; i < m ; i++) S->PLinv [i] = nextrow [leftmost [i]]++ ;
+        }
+        S->Sp.assign (m+1, 0) ;
+        for (Long i = 0 ; i < m ; i++) S->Sp [S->PLinv [i] + 1] = rowcount [i] ;
+        for (Long i = 0 ; i < m ; i++) S->Sp [i+1] += S->Sp [i] ;
+        S->Sj.resize (anz) ;
+        {
+            std::vector<Long> w (S->Sp.begin ( ), S->Sp.begin ( ) + m) ;
+            for (Long k = 0 ; k < n ; k++)
+            {
+                const Long col = S->Qfill [k] ;
+                for (Long p = Ap [col] ; p < Ap [col+1] ; p++) S->Sj [w [S->PLinv [Ai [p]]]++] = k ;
+            }
+        }
+
+        // ---- column counts of R (rows of R = columns of chol((AQ)'(AQ))) -----------------
+        // skeleton/least-common-ancestor counting (Gilbert, Ng, Peyton), each row of S
+        // visited at its leftmost column
+        std::vector<Long> cc (n, 0) ;
+        {
+            std::vector<Long> first (n, -1), maxfirst (n, -1), prevleaf (n, -1), anc (n) ;
+            for (Long j = 0 ; j < n ; j++)
+            {
+                // columns are in postorder: first[j] = first descendant of j
+                if (first [j] == -1) { first [j] = j ; cc [j] = 1 ; }
+                Long p = parent [j] ;
+                if (p != -1 && first [p] == -1) first [p] = first [j] ;
+                anc [j] = j ;
+            }
+            for (Long j = 0 ; j < n ; j++)
+            {
+                if (parent [j] != -1) cc [parent [j]]-- ;
+                for (Long row = S->Sleft [j] ; row < S->Sleft [j+1] ; row++)
+                {
+                    for (Long p = S->Sp [row] ; p < S->Sp [row+1] ; p++)
+                    {
+                        const Long i = S->Sj [p] ;
+                        if (i <= j || first [j] <= maxfirst [i]) continue ;
+                        maxfirst [i] = first [j] ;
+                        const Long jprev = prevleaf [i] ;
+                        prevleaf [i] = j ;
+                        cc [j]++ ;
+                        if (jprev != -1)
+                        {
+                            Long q = jprev ;
+                            while (q != anc [q]) q = anc [q] ;
+                            for (Long s = jprev ; s != q ; ) { Long sp = anc [s] ; anc [s] = q ; s = sp ; }
+                            cc [q]-- ;
+                        }
+                    }
+                }
+                if (parent [j] != -1) anc [j] = parent [j] ;
+            }
+            for (Long j = 0 ; j < n ; j++) if (parent [j] != -1) cc [parent [j]] += cc [j] ;
+        }
+        S->ColCount = cc ;
+
+        // ---- fundamental supernodes --------------------------------------------------
+        std::vector<Long> nchild (n, 0) ;
+        for (Long j = 0 ; j < n ; j++) if (parent [j] != -1) nchild [parent [j]]++ ;
+        std::vector<Long> super ;
+        for (Long j = 0 ; j < n ; j++)
+        {
+            bool join = (j > 0 && parent [j-1] == j && nchild [j] == 1 && cc [j] == cc [j-1] - 1) ;
+            if (!join) super.push_back (j) ;
+        }
+        super.push_back (n) ;
+        Long nf = (Long) super.size ( ) - 1 ;
+
+        // front tree
+        std::vector<Long> col2front (n) ;
+        for (Long f = 0 ; f < nf ; f++) for (Long j = super [f] ; j < super [f+1] ; j++) col2front [j] = f ;
+        std::vector<Long> fparent (nf) ;
+        for (Long f = 0 ; f < nf ; f++)
+        {
+            Long p = parent [super [f+1] - 1] ;
+            fparent [f] = (p == -1) ? nf : col2front [p] ;
+        }
+
+        // ---- relaxed amalgamation: merge a front into its parent when it is the parent's
+        // last child in column order (so the pivot ranges stay contiguous) and the merged
+        // front gains at most `relax` percent explicit zeros ----------------------------
+        if (relax > 0 && nf > 1)
+        {
+            // sizes: fp[f], fn[f] = cc of first column.  Merging child c (last columns end at
+            // super[p]) into parent p gives fp = fpc + fpp, fn = fpc + fnp (needs struct(c) minus
+            // pivots to be inside struct(p), true for any etree child), zeros added =
+            // fpc * (fpc + fnp) - (entries of the child's R block).
+            std::vector<Long> fp (nf), fnn (nf), rnz (nf) ;
+            std::vector<char> dead (nf, 0) ;
+            for (Long f = 0 ; f < nf ; f++)
+            {
+                fp [f] = super [f+1] - super [f] ;
+                fnn [f] = cc [super [f]] ;
+                rnz [f] = fp [f] * fnn [f] - fp [f] * (fp [f] - 1) / 2 ;
+            }
+            // process children-first; a child is adjacent to its parent iff super[c+1] == super[p]
+            // where c is the previous live front
+            std::vector<Long> firstcol (super.begin ( ), super.end ( ) - 1) ;
+            for (Long f = 0 ; f < nf ; f++)
+            {
+                const Long p = fparent [f] ;
+                if (p >= nf) continue ;
+                if (super [f+1] != firstcol [p]) continue ;            // not the adjacent child
+                const Long mfp = fp [f] + fp [p] ;
+                const Long mfn = fp [f] + fnn [p] ;
+                const Long mrnz = mfp * mfn - mfp * (mfp - 1) / 2 ;
+                const Long old = rnz [f] + rnz [p] ;
+                const bool small = (mfp <= 4) ;
+                if (small || (double) (mrnz - old) <= (double) relax * 0.01 * (double) mrnz)
+                {
+                    dead [f] = 1 ;
+                    firstcol [p] = firstcol [f] ;
+                    fp [p] = mfp ; fnn [p] = mfn ; rnz [p] = mrnz ;
+                    // f's children become p's children
+                    // (resolved below through the dead chain)
+                }
+            }
+            std::vector<Long> newsuper, newid (nf, -1) ;
+            for (Long f = 0 ; f < nf ; f++) if (!dead [f]) { newid [f] = (Long) newsuper.size ( ) ; newsuper.push_back (firstcol [f]) ; }
+            newsuper.push_back (n) ;
+            const Long nf2 = (Long) newsuper.size ( ) - 1 ;
+            std::vector<Long> np (nf2) ;
+            for (Long f = 0 ; f < nf ; f++)
+            {
+                if (dead [f]) continue ;
+                Long p = fparent [f] ;
+                while (p < nf && dead [p]) p = fparent [p] ;
+                np [newid [f]] = (p >= nf) ? nf2 : newid [p] ;
+            }
+            super.swap (newsuper) ;
+            fparent.swap (np) ;
+            nf = nf2 ;
+            for (Long f = 0 ; f < nf ; f++) for (Long j = super [f] ; j < super [f+1] ; j++) col2front [j] = f ;
+        }
+
+        S->nf = nf ;
+        S->Super = super ;
+        S->Parent.assign (nf+1, -1) ;
+        for (Long f = 0 ; f < nf ; f++) S->Parent [f] = fparent [f] ;
+        S->Parent [nf] = -1 ;
+        S->Childp.assign (nf+2, 0) ;
+        for (Long f = 0 ; f < nf ; f++) S->Childp [fparent [f] + 1]++ ;
+        for (Long f = 0 ; f <= nf ; f++) S->Childp [f+1] += S->Childp [f] ;
+        S->Child.assign (nf+1, 0) ;
+        {
+            std::vector<Long> w (S->Childp.begin ( ), S->Childp.begin ( ) + nf + 1) ;
+            for (Long f = 0 ; f < nf ; f++) S->Child [w [fparent [f]]++] = f ;
+        }
+        S->Post.resize (nf+1) ;
+        for (Long f = 0 ; f <= nf ; f++) S->Post [f] = f ;     // fronts are numbered in postorder
+
+        // ---- front patterns Rp, Rj ------------------------------------------------------
+        S->Rp.assign (nf+1, 0) ;
+        S->Rj.clear ( ) ;
+        {
+            std::vector<Long> mark (n, -1), cols ;
+            for (Long f = 0 ; f < nf ; f++)
+            {
+                const Long col1 = super [f], col2 = super [f+1] ;
+                cols.clear ( ) ;
+                for (Long j = col1 ; j < col2 ; j++) mark [j] = f ;
+                for (Long row = S->Sleft [col1] ; row < S->Sleft [col2] ; row++)
+                    for (Long p = S->Sp [row] ; p < S->Sp [row+1] ; p++)
+                    {
+                        const Long j = S->Sj [p] ;
+                        if (mark [j] != f) { mark [j] = f ; cols.push_back (j) ; }
+                    }
+                for (Long cp = S->Childp [f] ; cp < S->Childp [f+1] ; cp++)
+                {
+                    const Long c = S->Child [cp] ;
+                    const Long fpc = super [c+1] - super [c] ;
+                    for (Long p = S->Rp [c] + fpc ; p < S->Rp [c+1] ; p++)
+                    {
+                        const Long j = S->Rj [p] ;
+                        if (mark [j] != f) { mark [j] = f ; cols.push_back (j) ; }
+                    }
+                }
+                std::sort (cols.begin ( ), cols.end ( )) ;
+                for (Long j = col1 ; j < col2 ; j++) S->Rj.push_back (j) ;
+                S->Rj.insert (S->Rj.end ( ), cols.begin ( ), cols.end ( )) ;
+                S->Rp [f+1] = (Long) S->Rj.size ( ) ;
+            }
+        }
+        S->rjsize = (Long) S->Rj.size ( ) ;
+
+        // ---- Fm, Cm, map offsets, front-local Sj, flop count ----------------------------
+        // (spqr_analyze.cpp:646-902 with do_rank_detection = false)
+        S->Fm.assign (nf+1, 0) ; S->Cm.assign (nf+1, 0) ;
+        S->RjmapOffsets.assign (nf+1, 0) ; S->RimapOffsets.assign (nf+1, 0) ;
+        S->RjmapSize = 0 ; S->RimapSize = 0 ;
+        S->maxfn = 0 ; S->flopcount = 0 ; S->rnz = 0 ;
+        {
+            std::vector<Long> Fmap (n, -1), Stair ;
+            for (Long f = 0 ; f < nf ; f++)
+            {
+                const Long col1 = super [f], col2 = super [f+1] ;
+                const Long p1 = S->Rp [f], p2 = S->Rp [f+1] ;
+                const Long fp = col2 - col1, fn = p2 - p1 ;
+                S->maxfn = std::max (S->maxfn, fn) ;
+                for (Long p = p1 ; p < p2 ; p++) Fmap [S->Rj [p]] = p - p1 ;
+                Stair.assign (fn, 0) ;
+                for (Long j = 0 ; j < fp ; j++) Stair [j] = S->Sleft [col1+j+1] - S->Sleft [col1+j] ;
+                for (Long cp = S->Childp [f] ; cp < S->Childp [f+1] ; cp++)
+                {
+                    const Long c = S->Child [cp] ;
+                    const Long fpc = super [c+1] - super [c] ;
+                    const Long cm = S->Cm [c] ;
+                    for (Long ci = 0 ; ci < cm ; ci++) Stair [Fmap [S->Rj [S->Rp [c] + fpc + ci]]]++ ;
+                }
+                Long fm = 0 ;
+                for (Long j = 0 ; j < fn ; j++) { fm += Stair [j] ; Stair [j] = fm ; }
+                S->Fm [f] = fm ;
+                const Long rm = std::min (fm, fp) ;
+                const Long cn = fn - fp ;
+                S->Cm [f] = std::min (std::max (fm - rm, (Long) 0), cn) ;
+                S->rnz += rm*(rm+1)/2 + rm*(fn-rm) ;
+                S->RjmapOffsets [f] = S->RjmapSize ; S->RjmapSize += cn ;
+                S->RimapOffsets [f] = S->RimapSize ; S->RimapSize += S->Cm [f] ;
+                for (Long row = S->Sleft [col1] ; row < S->Sleft [col2] ; row++)
+                    for (Long p = S->Sp [row] ; p < S->Sp [row+1] ; p++) S->Sj [p] = Fmap [S->Sj [p]] ;
+                for (Long j = 0 ; j < fn ; j++)
+                {
+                    Long t = std::min (std::max (j+1, Stair [j]), fm) ;
+                    if (t > j)
+                    {
+                        double h = (double) (t - j) ;
+                        S->flopcount += 3*h + 4*h*(double) (fn-j-1) ;
+                    }
+                }
+            }
+        }
+
+        // ---- staging --------------------------------------------------------------------
+        S->Stagingp.assign (nf+2, 0) ; S->StageMap.assign (nf+1, 0) ;
+        S->FSize.assign (nf+1, 0) ; S->RSize.assign (nf+1, 0) ; S->SSize.assign (nf+1, 0) ;
+        S->FOffsets.assign (nf+1, 0) ; S->ROffsets.assign (nf+1, 0) ; S->SOffsets.assign (nf+1, 0) ;
+        S->numStages = 0 ;
+        S->gpuMemorySize = gpuMemorySize ;
+        int feasible = spqrgpu_amd_compute_front_staging (nf, S->Parent.data ( ), S->Childp.data ( ),
+            S->Child.data ( ), S->Fm.data ( ), S->Cm.data ( ), S->Rp.data ( ), S->Sp.data ( ), S->Sleft.data ( ),
+            S->Super.data ( ), S->Post.data ( ), S->RimapSize, S->RjmapSize, gpuMemorySize,
+            &S->numStages, S->Stagingp.data ( ), S->StageMap.data ( ),
+            (size_t *) S->FSize.data ( ), (size_t *) S->RSize.data ( ), (size_t *) S->SSize.data ( ),
+            S->FOffsets.data ( ), S->ROffsets.data ( ), S->SOffsets.data ( )) ;
+        if (!feasible) *status = 2 ;
+        return S ;
+    }
+    catch (std::bad_alloc &)
+    {
+        delete S ;
+        *status = 1 ;
+        return NULL ;
+    }
+}
+
+extern "C" void spqr_amd_symbolic_free (spqr_amd_symbolic *sym)
+{
+    delete sym ;
+}
+
+extern "C" const int64_t *spqr_amd_symbolic_array (const spqr_amd_symbolic *S, const char *name, int64_t *len)
+{
+    if (!S || !name) return NULL ;
+    const std::vector<Long> *v = NULL ;
+    #define PICK(x) if (!strcmp (name, #x)) v = &S->x ;
+    PICK (Qfill) PICK (PLinv) PICK (Sleft) PICK (Sp) PICK (Sj) PICK (Super) PICK (Rp) PICK (Rj)
+    PICK (Parent) PICK (Childp) PICK (Child) PICK (Post) PICK (Fm) PICK (Cm) PICK (RjmapOffsets)
+    PICK (RimapOffsets) PICK (Stagingp) PICK (StageMap) PICK (FSize) PICK (RSize) PICK (SSize)
+    PICK (FOffsets) PICK (ROffsets) PICK (SOffsets) PICK (ColCount)
+    #undef PICK
+    if (!v) return NULL ;
+    if (len) *len = (int64_t) v->size ( ) ;
+    return v->data ( ) ;
+}
+
+extern "C" double spqr_amd_symbolic_scalar (const spqr_amd_symbolic *S, const char *name)
+{
+    if (!S || !name) return -1 ;
+    #define PICK(x) if (!strcmp (name, #x)) return (double) S->x ;
+    PICK (m) PICK (n) PICK (anz) PICK (nf) PICK (maxfn) PICK (rjsize) PICK (RimapSize) PICK (RjmapSize)
+    PICK (numStages) PICK (flopcount) PICK (rnz)
+    #undef PICK
+    return -1 ;
+}

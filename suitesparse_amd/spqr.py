@@ -1,0 +1,185 @@
+"""Python mirror of the SPQR GPU glue, on top of the C ABI in include/spqrgpu_amd.h.
+
+Function names follow SPQR/Include/spqrgpu.hpp:9-82.  Plumbing only.
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Numeric(C.Structure):
+    """spqr_amd_numeric."""
+    _fields_ = [("nf", C.c_int64), ("rsize", C.c_int64), ("Rstack", C.POINTER(C.c_double)),
+                ("Rblock", C.POINTER(C.c_int64)), ("Rdead", C.POINTER(C.c_char)),
+                ("sumfrank", C.c_int64), ("maxfrank", C.c_int64), ("gpuKernelTime", C.c_double),
+                ("gpuFlops", C.c_int64), ("gpuNumKernelLaunches", C.c_int64),
+                ("numStagesRun", C.c_int64), ("assembleBytes", C.c_double)]
+
+
+_ARRAYS = ["Qfill", "PLinv", "Sleft", "Sp", "Sj", "Super", "Rp", "Rj", "Parent", "Childp", "Child",
+           "Post", "Fm", "Cm", "RjmapOffsets", "RimapOffsets", "Stagingp", "StageMap", "FSize",
+           "RSize", "SSize", "FOffsets", "ROffsets", "SOffsets", "ColCount"]
+_SCALARS = ["m", "n", "anz", "nf", "maxfn", "rjsize", "RimapSize", "RjmapSize", "numStages",
+            "flopcount", "rnz"]
+
+
+def _bind():
+    L = _lib.lib()
+    if getattr(L, "_spqr_bound", False):
+        return L
+    L.spqr_amd_analyze.restype = C.c_void_p
+    L.spqr_amd_analyze.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.c_size_t, C.POINTER(C.c_int)]
+    L.spqr_amd_symbolic_free.argtypes = [C.c_void_p]
+    L.spqr_amd_symbolic_array.restype = C.POINTER(C.c_int64)
+    L.spqr_amd_symbolic_array.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
+    L.spqr_amd_symbolic_scalar.restype = C.c_double
+    L.spqr_amd_symbolic_scalar.argtypes = [C.c_void_p, C.c_char_p]
+    L.spqrgpu_amd_factorize.restype = C.c_int
+    L.spqrgpu_amd_factorize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.POINTER(Numeric))]
+    L.spqr_amd_numeric_free.argtypes = [C.POINTER(Numeric)]
+    L.spqr_amd_rconvert.restype = C.c_int
+    L.spqr_amd_rconvert.argtypes = [C.c_void_p, C.POINTER(Numeric), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.spqrgpu_amd_compute_front_staging.restype = C.c_int
+    L.spqrgpu_amd_numfronts_in_stage.restype = C.c_int64
+    L._spqr_bound = True
+    return L
+
+
+class Symbolic:
+    """Owner of a spqr_amd_symbolic; arrays are exposed as numpy views by name."""
+
+    def __init__(self, handle, status):
+        self._h = handle
+        self.status = status
+        L = _bind()
+        for name in _SCALARS:
+            v = L.spqr_amd_symbolic_scalar(handle, name.encode())
+            setattr(self, name, v if name == "flopcount" else int(v))
+        for name in _ARRAYS:
+            ln = C.c_int64(0)
+            p = L.spqr_amd_symbolic_array(handle, name.encode(), C.byref(ln))
+            arr = np.ctypeslib.as_array(p, shape=(ln.value,)) if ln.value > 0 else np.zeros(0, np.int64)
+            setattr(self, name, arr)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _bind().spqr_amd_symbolic_free(self._h)
+            self._h = None
+
+
+def analyze(A, Q=None, relax=0, gpuMemorySize=0):
+    """spqr_amd_analyze: symbolic analysis + staging of A(:,Q) for the GPU path."""
+    L = _bind()
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    m, n = A.shape
+    Ap, Ai = _i64(A.indptr), _i64(A.indices)
+    Qa = None if Q is None else _i64(Q)
+    st = C.c_int(0)
+    h = L.spqr_amd_analyze(m, n, _p(Ap), _p(Ai), _p(Qa), relax, gpuMemorySize, C.byref(st))
+    if not h:
+        raise MemoryError("spqr_amd_analyze failed, status %d" % st.value)
+    return Symbolic(h, st.value)
+
+
+class NumericResult:
+    pass
+
+
+def factorize(sym, A):
+    """spqrgpu_amd_factorize + spqr_amd_rconvert: returns R (scipy CSC, sumfrank-by-n) and stats."""
+    L = _bind()
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    Ap, Ai, Ax = _i64(A.indptr), _i64(A.indices), np.ascontiguousarray(A.data, dtype=np.float64)
+    out = C.POINTER(Numeric)()
+    code = L.spqrgpu_amd_factorize(sym._h, _p(Ap), _p(Ai), _p(Ax), C.byref(out))
+    if code != 0:
+        raise RuntimeError("spqrgpu_amd_factorize failed with code %d" % code)
+    num = out.contents
+    n = sym.n
+    Rp = np.zeros(n + 1, dtype=np.int64)
+    L.spqr_amd_rconvert(sym._h, out, _p(Rp), None, None)
+    Ri = np.zeros(max(int(Rp[n]), 1), dtype=np.int64)
+    Rx = np.zeros(max(int(Rp[n]), 1), dtype=np.float64)
+    L.spqr_amd_rconvert(sym._h, out, _p(Rp), _p(Ri), _p(Rx))
+    res = NumericResult()
+    res.rank = int(num.sumfrank)
+    res.maxfrank = int(num.maxfrank)
+    res.R = sp.csc_matrix((Rx[:Rp[n]], Ri[:Rp[n]], Rp), shape=(max(res.rank, 0), n))
+    res.Rdead = np.frombuffer(C.string_at(num.Rdead, n), dtype=np.int8).copy() if n > 0 else np.zeros(0, np.int8)
+    res.gpuKernelTime = float(num.gpuKernelTime)
+    res.gpuFlops = int(num.gpuFlops)
+    res.gpuNumKernelLaunches = int(num.gpuNumKernelLaunches)
+    res.numStagesRun = int(num.numStagesRun)
+    res.assembleBytes = float(num.assembleBytes)
+    L.spqr_amd_numeric_free(out)
+    return res
+
+
+def spqrgpu_computeFrontStaging(nf, Parent, Childp, Child, Fm, Cm, Rp, Sp, Sleft, Super, Post,
+                                RimapSize, RjmapSize, gpuMemorySize):
+    """spqrgpu_computeFrontStaging (SPQR/Include/spqrgpu.hpp:16-57) on caller arrays.
+    Returns dict(feasible, numStages, Stagingp, StageMap, FSize, RSize, SSize, FOffsets, ROffsets, SOffsets)."""
+    L = _bind()
+    a = [_i64(x) for x in (Parent, Childp, Child, Fm, Cm, Rp, Sp, Sleft, Super, Post)]
+    numStages = C.c_int64(0)
+    Stagingp = np.zeros(nf + 2, np.int64)
+    StageMap = np.zeros(nf + 1, np.int64)
+    FSize, RSize, SSize = (np.zeros(nf + 1, np.uint64) for _ in range(3))
+    FOff, ROff, SOff = (np.zeros(nf + 1, np.int64) for _ in range(3))
+    L.spqrgpu_amd_compute_front_staging.argtypes = [C.c_int64] + [C.c_void_p] * 10 + [
+        C.c_int64, C.c_int64, C.c_size_t, C.POINTER(C.c_int64)] + [C.c_void_p] * 8
+    ok = L.spqrgpu_amd_compute_front_staging(
+        nf, *[_p(x) for x in a], RimapSize, RjmapSize, gpuMemorySize, C.byref(numStages),
+        _p(Stagingp), _p(StageMap), _p(FSize), _p(RSize), _p(SSize), _p(FOff), _p(ROff), _p(SOff))
+    return dict(feasible=bool(ok), numStages=int(numStages.value), Stagingp=Stagingp, StageMap=StageMap,
+                FSize=FSize, RSize=RSize, SSize=SSize, FOffsets=FOff, ROffsets=ROff, SOffsets=SOff)
+
+
+def spqrgpu_buildAssemblyMaps(sym, Sx):
+    """spqrgpu_buildAssemblyMaps (SPQR/Include/spqrgpu.hpp:59-82) for a Symbolic; returns
+    (Stair, Rjmap, Rimap, cpuS) with cpuS a structured array (findex, value)."""
+    L = _bind()
+    nf, n = sym.nf, sym.n
+    Fmap = np.zeros(max(n, 1), np.int64)
+    Stair = np.zeros(max(int(sym.Rp[nf]), 1), np.int64)
+    Rjmap = np.zeros(max(sym.RjmapSize, 1), np.int32)
+    Rimap = np.zeros(max(sym.RimapSize, 1), np.int32)
+    cpuS = np.zeros(max(sym.anz, 1), dtype=np.dtype([("findex", np.int64), ("value", np.float64)]))
+    Sx = np.ascontiguousarray(Sx, dtype=np.float64)
+    L.spqrgpu_amd_build_assembly_maps.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 19
+    L.spqrgpu_amd_build_assembly_maps.restype = None
+    L.spqrgpu_amd_build_assembly_maps(
+        nf, n, _p(Fmap), _p(sym.Post), _p(sym.Super), _p(sym.Rp), _p(sym.Rj), _p(sym.Sleft), _p(sym.Sp),
+        _p(sym.Sj), _p(Sx), _p(sym.Fm), _p(sym.Cm), _p(sym.Childp), _p(sym.Child), _p(Stair), _p(Rjmap),
+        _p(sym.RjmapOffsets), _p(Rimap), _p(sym.RimapOffsets), _p(cpuS))
+    return Stair, Rjmap, Rimap, cpuS
+
+
+def s_values(sym, A):
+    """Sx: the values of S = A(P,Q) in row order (spqr_stranspose2)."""
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    Sx = np.zeros(sym.anz)
+    w = sym.Sp[:-1].copy()
+    for k in range(sym.n):
+        col = sym.Qfill[k]
+        for p in range(A.indptr[col], A.indptr[col + 1]):
+            r = sym.PLinv[A.indices[p]]
+            Sx[w[r]] = A.data[p]
+            w[r] += 1
+    return Sx

@@ -1,0 +1,199 @@
+"""CPU tests: oracle vs LAPACK, host-side integer logic vs the oracle (bit exact), C ABI surface."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import suitesparse_amd as ss
+from oracle import oracle
+from suitesparse_amd import _lib, problems, spqr
+from tests.util import demo_rand_front, gram_resid, r_rel_diff, rownorm_sign, stair_front
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------- oracle pinning
+
+@pytest.mark.parametrize("count,m,n", [(2, 8, 8), (2, 12, 8), (2, 64, 32), (1, 100, 200)])
+def test_oracle_demo_known_answer(count, m, n):
+    """The dense demo's assertion ||triu(R)'triu(R) - A'A|| / ||A'A|| <= 1e-12
+    (GPUQREngine/Demo/gpuqrengine_demo.cpp:94-100) on its four geometries (:305-308)."""
+    for i in range(count):
+        A = demo_rand_front(m, n, seed_state=1 + i)
+        R = oracle.front_qr(A)
+        assert gram_resid(R[:min(m, n)], A) <= 1e-12
+        assert np.all(np.tril(R, -1) == 0.0)
+
+
+@pytest.mark.parametrize("m,n", [(5, 5), (40, 17), (17, 40), (300, 64), (128, 128)])
+def test_oracle_matches_lapack_up_to_row_signs(m, n):
+    rng = np.random.default_rng(m * 131 + n)
+    A = rng.uniform(-1, 1, size=(m, n))
+    R = oracle.front_qr(A)[:min(m, n)]
+    Rl = np.linalg.qr(A, mode="r")
+    assert r_rel_diff(rownorm_sign(R), rownorm_sign(Rl)) <= 1e-13
+    # device convention: non-negative diagonal, except where nothing lies below it
+    # (sigma = 0 keeps the entry as it is, factorize_vt.cu:277-283)
+    kk = min(m, n) - (1 if m <= n else 0)
+    assert np.all(np.diag(R)[:kk] >= 0)
+
+
+def test_oracle_staircase_front():
+    rng = np.random.default_rng(2)
+    A = stair_front(200, 80, rng)
+    st = oracle.find_staircase(A)
+    R1 = oracle.front_qr(A, st)
+    R0 = oracle.front_qr(A)
+    assert np.allclose(R1[:80], R0[:80], rtol=0, atol=1e-13 * np.abs(R0).max())
+
+
+# ---------------------------------------------------------------- host functions vs oracle
+
+@pytest.mark.parametrize("mem", [0, 1, 2, 50000, 10**6, 2**20 + 104 * 100000 + 5, 10**8, 10**10, 2**40])
+def test_max_queue_size(mem):
+    assert ss.ssgpu_maxQueueSize(mem) == oracle.max_queue_size(mem)
+
+
+def test_find_staircase_matches_oracle():
+    rng = np.random.default_rng(13)
+    for shape in [(90, 40), (10, 30), (1, 1), (64, 64)]:
+        A = stair_front(*shape, rng)
+        f = ss.Front(0, ss.EMPTY, *shape)
+        f.F = A
+        assert np.array_equal(ss.GPUQREngine_FindStaircase(f), oracle.find_staircase(A))
+
+
+def _cases():
+    yield "2d-12", problems.stacked_ls((12, 12)), problems.nested_dissection((12, 12), leaf=3)
+    yield "2d-20x9", problems.stacked_ls((20, 9)), problems.nested_dissection((20, 9), leaf=4)
+    yield "3d-6", problems.stacked_ls((6, 6, 6)), problems.nested_dissection((6, 6, 6), leaf=2)
+    rng = np.random.default_rng(4)
+    R = sp.random(60, 35, density=0.08, random_state=4, format="csc") + sp.vstack(
+        [sp.identity(35), sp.csc_matrix((25, 35))])
+    yield "random", sp.csc_matrix(R), rng.permutation(35)
+
+
+@pytest.mark.parametrize("name,A,Q", list(_cases()), ids=[c[0] for c in _cases()])
+@pytest.mark.parametrize("relax", [0, 20])
+def test_symbolic_consistency(name, A, Q, relax):
+    sym = spqr.analyze(A, Q, relax=relax, gpuMemorySize=2**33)
+    n, nf = sym.n, sym.nf
+    assert sorted(sym.Qfill.tolist()) == list(range(n))
+    # column counts against a brute-force symbolic Cholesky of (AQ)'(AQ)
+    AQ = A[:, sym.Qfill].toarray()
+    pat = (AQ.T @ AQ) != 0
+    for k in range(n):
+        nz = np.nonzero(pat[k + 1:, k])[0] + k + 1
+        pat[np.ix_(nz, nz)] = True
+    cc = 1 + np.array([pat[k + 1:, k].sum() for k in range(n)])
+    assert np.array_equal(cc, sym.ColCount)
+    # every front pattern contains the pattern of each of its pivot columns' R row
+    for f in range(nf):
+        cols = set(sym.Rj[sym.Rp[f]:sym.Rp[f + 1]].tolist())
+        for j in range(sym.Super[f], sym.Super[f + 1]):
+            assert set(np.nonzero(pat[j:, j])[0] + j) | {j} <= cols
+        if relax == 0:
+            assert len(cols) == cc[sym.Super[f]]
+    # tree conventions of spqr_analyze
+    assert sym.Parent[nf] == -1 and sym.Post[nf] == nf and sym.Childp[nf + 1] == nf
+    assert all(sym.Parent[f] > f for f in range(nf))
+    assert sym.Sleft[n + 1] == sym.m and sym.Sp[sym.m] == sym.anz
+
+
+@pytest.mark.parametrize("name,A,Q", list(_cases()), ids=[c[0] for c in _cases()])
+def test_assembly_maps_bit_exact(name, A, Q):
+    sym = spqr.analyze(A, Q, gpuMemorySize=2**33)
+    Sx = spqr.s_values(sym, A)
+    got = spqr.spqrgpu_buildAssemblyMaps(sym, Sx)
+    ref = oracle.build_assembly_maps(sym, Sx)
+    for g, r in zip(got, ref):
+        assert g.tobytes() == r.tobytes()
+    # Stair ends one past the last row of each column and the last one is fm
+    Stair = got[0]
+    for f in range(sym.nf):
+        st = Stair[sym.Rp[f]:sym.Rp[f + 1]]
+        assert np.all(np.diff(st) >= 0) and st[-1] == sym.Fm[f]
+
+
+@pytest.mark.parametrize("name,A,Q", list(_cases()), ids=[c[0] for c in _cases()])
+@pytest.mark.parametrize("mem", [0, 1, 2**21, 2**22 + 12345, 11_000_000, 2**33])
+def test_staging_bit_exact(name, A, Q, mem):
+    sym = spqr.analyze(A, Q, gpuMemorySize=2**33)
+    args = (sym.nf, sym.Parent, sym.Childp, sym.Child, sym.Fm, sym.Cm, sym.Rp, sym.Sp, sym.Sleft, sym.Super,
+            sym.Post, sym.RimapSize, sym.RjmapSize, mem)
+    got = spqr.spqrgpu_computeFrontStaging(*args)
+    ref = oracle.compute_front_staging(*args)
+    assert got["feasible"] == ref["feasible"] and got["numStages"] == ref["numStages"]
+    if got["feasible"]:
+        ns, nf = got["numStages"], sym.nf
+        for key in ("Stagingp",):
+            assert np.array_equal(got[key][:ns + 1], ref[key][:ns + 1])
+        for key in ("FSize", "RSize", "SSize"):
+            assert np.array_equal(got[key][:ns], ref[key][:ns])
+        for key in ("StageMap", "FOffsets", "ROffsets", "SOffsets"):
+            assert np.array_equal(got[key][:nf], ref[key][:nf])
+
+
+def test_staging_quirks_recorded_from_the_reference():
+    """Outcomes observed with the reference's own function (tiny memory -> empty stage 0 and one
+    front per stage; gpuMemorySize = 1 -> infeasible; huge memory -> one stage)."""
+    A = problems.stacked_ls((12, 12))
+    Q = problems.nested_dissection((12, 12), leaf=3)
+    sym = spqr.analyze(A, Q, gpuMemorySize=2**33)
+    args = (sym.nf, sym.Parent, sym.Childp, sym.Child, sym.Fm, sym.Cm, sym.Rp, sym.Sp, sym.Sleft, sym.Super,
+            sym.Post, sym.RimapSize, sym.RjmapSize)
+    one = spqr.spqrgpu_computeFrontStaging(*args, 10**10)
+    assert one["feasible"] and one["numStages"] == 1
+    assert one["SSize"][0] == sym.anz
+    zero = spqr.spqrgpu_computeFrontStaging(*args, 0)
+    assert zero["feasible"] and list(zero["Stagingp"][:4]) == [0, 0, 1, 2]
+    bad = spqr.spqrgpu_computeFrontStaging(*args, 1)
+    assert not bad["feasible"] and bad["numStages"] == 0
+
+
+def test_oracle_multifrontal_matches_dense_qr():
+    """R from the CPU multifrontal oracle equals LAPACK's R of A(:,Qfill) up to row signs."""
+    for name, A, Q in _cases():
+        sym = spqr.analyze(A, Q, gpuMemorySize=2**33)
+        Farena, FOff = oracle.multifrontal(sym, spqr.s_values(sym, A))
+        R = oracle.r_from_fronts(sym, Farena, FOff)
+        Rl = np.linalg.qr(A[:, sym.Qfill].toarray(), mode="r")
+        assert R.shape[0] == sym.n
+        assert r_rel_diff(rownorm_sign(R), rownorm_sign(Rl)) <= 1e-12, name
+
+
+def test_flopcount_formula():
+    """flopcount = sum over fronts/columns of 3h + 4h(fn-j-1) (spqr_analyze.cpp:888-902); for a
+    dense m-by-n front that is about 2n^2(m - n/3)."""
+    A = sp.csc_matrix(np.ones((50, 20)))
+    sym = spqr.analyze(A, None)
+    assert sym.nf == 1 and sym.Fm[0] == 50
+    m, n = 50, 20
+    want = sum(3 * (m - j) + 4 * (m - j) * (n - j - 1) for j in range(n))
+    assert sym.flopcount == want
+
+
+# ---------------------------------------------------------------- C ABI surface
+
+def test_library_exports_every_declared_symbol():
+    names = []
+    for hdr in ("gpuqrengine_amd.h", "spqrgpu_amd.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names += re.findall(r"\b((?:gpuqr|spqrgpu_amd|spqr_amd)_[a-z_]+)\s*\(", txt)
+    names = sorted(set(names))
+    assert len(names) >= 15
+    L = C.CDLL(_lib.LIB_PATH)
+    for nme in names:
+        assert hasattr(L, nme), nme
+
+
+def test_error_codes_without_compute():
+    L = _lib.lib()
+    assert L.gpuqr_version() >= 1000
+    assert L.gpuqr_factor_dense(0, None, 0, None) == _lib.GPUQR_SUCCESS
+    assert L.gpuqr_factor_sparse(0, None, 3, None, None, None, None) == _lib.GPUQR_GPUERROR
+    assert L.gpuqr_front_flops(4096, 2048, None) > 2 * 2048 ** 2 * (4096 - 2048 / 3)

@@ -1,0 +1,92 @@
+"""GPU parity of the sparse path: S-assembly, pack-assembly, staging/limbo and the numeric
+driver against the CPU oracle (same symbolic structure) and LAPACK (R is unique up to row signs)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import oracle
+from suitesparse_amd import problems, spqr
+from tests.util import r_rel_diff, rownorm_sign
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    yield "2d-12", problems.stacked_ls((12, 12)), problems.nested_dissection((12, 12), leaf=3)
+    yield "2d-40", problems.stacked_ls((40, 40)), problems.nested_dissection((40, 40), leaf=4)
+    yield "2d-33x17", problems.stacked_ls((33, 17)), problems.nested_dissection((33, 17), leaf=4)
+    yield "3d-9", problems.stacked_ls((9, 9, 9)), problems.nested_dissection((9, 9, 9), leaf=2)
+    rng = np.random.default_rng(4)
+    R = sp.random(300, 120, density=0.03, random_state=4, format="csc") + sp.vstack(
+        [sp.identity(120), sp.csc_matrix((180, 120))])
+    yield "random", sp.csc_matrix(R), rng.permutation(120)
+    yield "natural-order", problems.stacked_ls((10, 10)), None
+
+
+CASES = list(_cases())
+
+
+def _dense_R(res, n):
+    R = np.zeros((n, n))
+    Rd = res.R.toarray()
+    R[:Rd.shape[0]] = Rd
+    return R
+
+
+@pytest.mark.parametrize("name,A,Q", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("relax", [0, 20])
+def test_sparse_qr_one_stage(name, A, Q, relax):
+    sym = spqr.analyze(A, Q, relax=relax, gpuMemorySize=2**34)
+    assert sym.numStages == 1
+    res = spqr.factorize(sym, A)
+    n = sym.n
+    assert res.rank == n and res.numStagesRun == 1
+    R = _dense_R(res, n)
+    # vs LAPACK on the permuted dense matrix
+    Rl = np.linalg.qr(A[:, sym.Qfill].toarray(), mode="r")
+    assert r_rel_diff(rownorm_sign(R), rownorm_sign(Rl)) <= 1e-12
+    # vs the CPU oracle: same fronts, same maps
+    Farena, FOff = oracle.multifrontal(sym, spqr.s_values(sym, A))
+    Ro = oracle.r_from_fronts(sym, Farena, FOff)
+    assert r_rel_diff(rownorm_sign(R), rownorm_sign(Ro)) <= 1e-12
+    # the pattern of R is the symbolic one: nnz == rnz and nothing outside the front patterns
+    assert res.R.nnz == sym.rnz
+    # ||R'R - (AQ)'(AQ)||_1 / ||A'A||_1 (check_r_factor, SPQR/Tcov/qrtest.cpp:1218-1257)
+    AQ = A[:, sym.Qfill].toarray()
+    G = AQ.T @ AQ
+    assert np.linalg.norm(R.T @ R - G, 1) / np.linalg.norm(G, 1) <= 1e-12
+
+
+@pytest.mark.parametrize("name,A,Q", CASES[:4], ids=[c[0] for c in CASES[:4]])
+@pytest.mark.parametrize("mem", [0, 10_700_000, 11_200_000])
+def test_sparse_qr_staged_equals_one_stage(name, A, Q, mem):
+    """Shrinking the declared device memory forces several stages and the host "limbo" round trip
+    of contribution blocks (the reference tests staging the same way, SPQR/Tcov/qrtest.cpp:2660-2684).
+    The factor must not depend on the staging."""
+    one = spqr.factorize(spqr.analyze(A, Q, gpuMemorySize=2**34), A)
+    sym = spqr.analyze(A, Q, gpuMemorySize=mem)
+    if sym.status == 2:
+        pytest.skip("infeasible at this size")
+    res = spqr.factorize(sym, A)
+    if mem == 0:
+        assert res.numStagesRun == sym.nf + 1
+    assert res.rank == one.rank
+    assert (res.R != one.R).nnz == 0 or np.abs((res.R - one.R)).max() <= 1e-13 * np.abs(one.R).max()
+
+
+def test_infeasible_memory_is_reported():
+    A = problems.stacked_ls((12, 12))
+    sym = spqr.analyze(A, None, gpuMemorySize=1)
+    assert sym.status == 2 and sym.numStages == 0
+    with pytest.raises(RuntimeError):
+        spqr.factorize(sym, A)
+
+
+def test_rank_deficient_hits_the_wall():
+    """Structurally rank-deficient input: pivot columns past the bottom of a front are dead
+    (spqrgpu_kernel.cpp:763-771); rank = sum of front ranks."""
+    A = sp.csc_matrix(np.array([[1., 2, 0, 0], [0, 0, 0, 3.], [0, 0, 0, 0]]))
+    sym = spqr.analyze(A, None, gpuMemorySize=2**30)
+    res = spqr.factorize(sym, A)
+    assert res.rank < 4 and res.rank == int(sum(min(sym.Fm[f], sym.Super[f + 1] - sym.Super[f]) for f in range(sym.nf)))
+    assert res.Rdead.sum() == 4 - res.rank
