@@ -121,6 +121,22 @@ int64_t gpuqr_front_flops (int64_t fm, int64_t fn, const int64_t *Stair);
 void gpuqr_set_allocator (void *(*malloc_fn) (size_t), void *(*calloc_fn) (size_t, size_t),
                           void (*free_fn) (void *));
 
+/* Per-kernel profile of the engine's own launches, measured with HIP events on
+ * the stream they run on (no counterpart in the reference beyond its -DTIMING
+ * total, GPUQREngine/Source/Scheduler/Scheduler_LaunchKernel.cpp:46-64).
+ * Kernel ids: 0..3 factorize (32/64/128/256-row tiers), 4..7 apply (same
+ * tiers), 8 assembly.  While enabled every engine call adds to the totals:
+ * launch time in ms, launches, tasks, algorithmic flops and bytes. */
+void gpuqr_profile_enable (int on);
+void gpuqr_profile_reset (void);
+int  gpuqr_profile_get (int kernel_id, double *ms, int64_t *launches, int64_t *tasks,
+                        double *flops, double *bytes);
+
+/* The engine keeps two streams, two events and grow-only task/VT buffers per
+ * device between calls (the reference rebuilds its Scheduler every call,
+ * GPUQREngine/Source/GPUQREngine_Internal.cpp:34-51).  This frees them. */
+void gpuqr_finalize (void);
+
 /* Number of HIP devices visible, or 0 (never fails). */
 int gpuqr_device_count (void);
 

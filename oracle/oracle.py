@@ -141,3 +141,17 @@ def r_from_fronts(sym, Farena, FOff):
             R[row1 + i, cols[i:]] = F[i, i:]
         row1 += rk
     return R
+
+
+def front_qr_batch(mats, nthreads=1):
+    """Factorize a list of fronts in place on the CPU (OpenMP over fronts); returns seconds."""
+    import time
+    fm = _i64([a.shape[0] for a in mats])
+    fn = _i64([a.shape[1] for a in mats])
+    F = np.concatenate([np.ascontiguousarray(a, dtype=np.float64).ravel() for a in mats])
+    f = lib().oracle_front_qr_batch
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+    t0 = time.perf_counter()
+    f(_p(F), _p(fm), _p(fn), len(mats), nthreads)
+    return time.perf_counter() - t0

@@ -61,6 +61,7 @@ void oracle_front_qr (double *F, Long fm, Long fn, const Long *Stair)
 {
     Long kmax = (fm < fn) ? fm : fn ;
     double *v = (double *) malloc ((size_t) (fm > 0 ? fm : 1) * sizeof (double)) ;
+    double *z = (double *) malloc ((size_t) (fn > 0 ? fn : 1) * sizeof (double)) ;
     Long e = 0 ;
     for (Long k = 0 ; k < kmax ; k++)
     {
@@ -93,15 +94,25 @@ void oracle_front_qr (double *F, Long fm, Long fn, const Long *Stair)
         for (Long i = k+1 ; i < e ; i++) F [i*fn+k] = 0 ;
         if (tau != 0)
         {
-            for (Long j = k+1 ; j < fn ; j++)
+            /* z = -tau v'A and A += v z, walking the row-major front row by row;
+             * each z [j] still sums over i in increasing order */
+            for (Long j = k+1 ; j < fn ; j++) z [j] = 0 ;
+            for (Long i = k ; i < e ; i++)
             {
-                double z = 0 ;
-                for (Long i = k ; i < e ; i++) z += v [i] * F [i*fn+j] ;
-                z *= -tau ;
-                for (Long i = k ; i < e ; i++) F [i*fn+j] += v [i] * z ;
+                const double vi = v [i] ;
+                const double *Fi = F + i*fn ;
+                for (Long j = k+1 ; j < fn ; j++) z [j] += vi * Fi [j] ;
+            }
+            for (Long j = k+1 ; j < fn ; j++) z [j] *= -tau ;
+            for (Long i = k ; i < e ; i++)
+            {
+                const double vi = v [i] ;
+                double *Fi = F + i*fn ;
+                for (Long j = k+1 ; j < fn ; j++) Fi [j] += vi * z [j] ;
             }
         }
     }
+    free (z) ;
     free (v) ;
 }
 
@@ -319,4 +330,16 @@ void oracle_multifrontal
                 Farena + FOffsets [pid], pn, Rimap + RimapOffsets [f], Rjmap + RjmapOffsets [f]) ;
         }
     }
+}
+
+/* A batch of independent fronts, one thread per front at a time: the CPU
+ * baseline leg of the benchmark.  F holds the fronts back to back. */
+void oracle_front_qr_batch (double *F, const Long *fm, const Long *fn, Long nfronts, int nthreads)
+{
+    Long *off = (Long *) malloc ((size_t) (nfronts + 1) * sizeof (Long)) ;
+    off [0] = 0 ;
+    for (Long k = 0 ; k < nfronts ; k++) off [k+1] = off [k] + fm [k] * fn [k] ;
+    #pragma omp parallel for schedule(dynamic,1) num_threads(nthreads)
+    for (Long k = 0 ; k < nfronts ; k++) oracle_front_qr (F + off [k], fm [k], fn [k], NULL) ;
+    free (off) ;
 }

@@ -34,7 +34,7 @@
 #include "../../include/gpuqrengine_amd.h"
 
 extern "C" int        qr_task_kernel_id (int type, int tier) ;
-extern "C" hipError_t qr_launch_tasks (int kid, const QrTask *d_tasks, int ntasks, hipStream_t stream) ;
+extern "C" hipError_t qr_launch_tasks (int kid, const QrTask *d_tasks, const QrRef *d_refs, int nrefs, hipStream_t stream) ;
 extern "C" hipError_t qr_kernels_init (void) ;
 
 #define QR_NKERNELS 9
@@ -123,7 +123,31 @@ struct SchedTask
     QrTask  t ;
     int32_t round ;
     int64_t vt ;        // VT tile index or -1
+    int32_t nblk ;      // workgroups this task is run by (apply: column blocks; else 1)
+    double  flops ;     // algorithmic flops of this task
+    double  bytes ;     // algorithmic (minimum) bytes it moves to and from memory
 } ;
+
+// -----------------------------------------------------------------------------
+// optional per-kernel profile (HIP events around every launch)
+// -----------------------------------------------------------------------------
+
+struct KernelProfile { double ms, flops, bytes ; int64_t launches, tasks ; } ;
+static int g_profile_on = 0 ;
+static KernelProfile g_profile [QR_NKERNELS] ;
+
+extern "C" void gpuqr_profile_enable (int on) { g_profile_on = on ; }
+extern "C" void gpuqr_profile_reset (void) { memset (g_profile, 0, sizeof (g_profile)) ; }
+extern "C" int gpuqr_profile_get (int kid, double *ms, int64_t *launches, int64_t *tasks, double *flops, double *bytes)
+{
+    if (kid < 0 || kid >= QR_NKERNELS) return -1 ;
+    if (ms) *ms = g_profile [kid].ms ;
+    if (launches) *launches = g_profile [kid].launches ;
+    if (tasks) *tasks = g_profile [kid].tasks ;
+    if (flops) *flops = g_profile [kid].flops ;
+    if (bytes) *bytes = g_profile [kid].bytes ;
+    return 0 ;
+}
 
 struct Plan
 {
@@ -248,6 +272,9 @@ static int32_t plan_front
             for (int s = 0 ; s < fr.nseg ; s++) { pt.seg_row [s] = fr.segs [s].row ; pt.seg_n [s] = fr.segs [s].n ; }
             st.round = rF0 + fr.level ;
             st.vt = fr.vt ;
+            st.nblk = 1 ;
+            st.flops = (double) flops_factorize (fr.K, w, trailing) ;
+            st.bytes = 16.0 * fr.K * w + (trailing ? 8.0 * QR_VT_DOUBLES : 0.0) ;
             plan.tasks.push_back (st) ;
         }
         done = std::max (done, rF0 + nlevels - 1) ;
@@ -256,46 +283,47 @@ static int32_t plan_front
         // ---- apply tasks ---------------------------------------------------------
         if (trailing)
         {
+            // All trailing tiles carry the same round number (they were all updated by the same
+            // rounds of the previous panel), so one apply task per factorize task covers the whole
+            // trailing width; the kernel cuts it into column blocks, one workgroup each.
             const int64_t t0 = p + 1 ;
-            int64_t bt = 4 ;                    // column tiles per apply task (128 columns)
+            int64_t bt = 4 ;                    // column tiles per workgroup (128 columns)
             while ((int64_t) frefs.size ( ) * ((ntiles - t0 + bt - 1) / bt) > 16384 && bt < 64) bt *= 2 ;
+            const int64_t cb = t0 * QR_PANEL_W ;
+            const int64_t ce = fn ;
+            const int64_t nblk = (ntiles - t0 + bt - 1) / bt ;
+            int32_t ready = tileround [t0] ;
+            for (int64_t t = t0 ; t < ntiles ; t++) ready = std::max (ready, tileround [t]) ;
             for (int32_t lv = 0 ; lv < nlevels ; lv++)
             {
-                for (int64_t tb = t0 ; tb < ntiles ; tb += bt)
+                const int32_t round = std::max (ready, rF0 + lv) + 1 ;
+                for (size_t i = 0 ; i < frefs.size ( ) ; i++)
                 {
-                    const int64_t te = std::min (tb + bt, ntiles) ;
-                    int32_t ready = rF0 + lv ;
-                    for (int64_t t = tb ; t < te ; t++) ready = std::max (ready, tileround [t]) ;
-                    const int32_t round = ready + 1 ;
-                    const int64_t cb = tb * QR_PANEL_W ;
-                    const int64_t ce = std::min (te * QR_PANEL_W, fn) ;
-                    bool any = false ;
-                    for (size_t i = 0 ; i < frefs.size ( ) ; i++)
-                    {
-                        const FRef &fr = frefs [i] ;
-                        if (fr.level != lv) continue ;
-                        any = true ;
-                        plan.flops += flops_apply (fr.K, w, ce - cb) ;
-                        if (!emit) continue ;
-                        SchedTask st ;
-                        memset (&st, 0, sizeof (st)) ;
-                        st.t.type = QR_TASK_APPLY ;
-                        st.t.tier = tier_of (fr.K) ;
-                        QrPanelTask &pt = st.t.u.panel ;
-                        pt.F = F ; pt.VT = NULL ; pt.ld = (int32_t) fn ; pt.col0 = (int32_t) c0 ; pt.w = (int32_t) w ;
-                        pt.K = fr.K ; pt.nseg = fr.nseg ; pt.c_begin = (int32_t) cb ; pt.c_end = (int32_t) ce ;
-                        for (int s = 0 ; s < fr.nseg ; s++) { pt.seg_row [s] = fr.segs [s].row ; pt.seg_n [s] = fr.segs [s].n ; }
-                        st.round = round ;
-                        st.vt = fr.vt ;
-                        plan.tasks.push_back (st) ;
-                    }
-                    if (any)
-                    {
-                        for (int64_t t = tb ; t < te ; t++) tileround [t] = round ;
-                        done = std::max (done, round) ;
-                    }
+                    const FRef &fr = frefs [i] ;
+                    if (fr.level != lv) continue ;
+                    plan.flops += flops_apply (fr.K, w, ce - cb) ;
+                    if (!emit) continue ;
+                    SchedTask st ;
+                    memset (&st, 0, sizeof (st)) ;
+                    st.t.type = QR_TASK_APPLY ;
+                    st.t.tier = tier_of (fr.K) ;
+                    QrPanelTask &pt = st.t.u.panel ;
+                    pt.F = F ; pt.VT = NULL ; pt.ld = (int32_t) fn ; pt.col0 = (int32_t) c0 ; pt.w = (int32_t) w ;
+                    pt.K = fr.K ; pt.nseg = fr.nseg ; pt.c_begin = (int32_t) cb ; pt.c_end = (int32_t) ce ;
+                    pt.cb_cols = (int32_t) (bt * QR_PANEL_W) ;
+                    for (int s = 0 ; s < fr.nseg ; s++) { pt.seg_row [s] = fr.segs [s].row ; pt.seg_n [s] = fr.segs [s].n ; }
+                    st.round = round ;
+                    st.vt = fr.vt ;
+                    st.nblk = (int32_t) nblk ;
+                    st.flops = (double) flops_apply (fr.K, w, ce - cb) ;
+                    // A read + written once; V (K x 32) and the VT tile read once per workgroup
+                    st.bytes = 16.0 * fr.K * (double) (ce - cb) + (double) nblk * (8.0 * fr.K * w + 8.0 * QR_VT_DOUBLES) ;
+                    plan.tasks.push_back (st) ;
                 }
+                ready = round ;
+                done = std::max (done, round) ;
             }
+            for (int64_t t = t0 ; t < ntiles ; t++) tileround [t] = ready ;
         }
     }
     return done ;
@@ -321,14 +349,88 @@ extern "C" int64_t gpuqr_front_flops (int64_t fm, int64_t fn, const int64_t *Sta
         hipGetErrorString (e_), __FILE__, __LINE__) ; \
     code = (e_ == hipErrorOutOfMemory) ? GPUQR_OUTOFMEMORY : GPUQR_GPUERROR ; goto cleanup ; } } while (0)
 
+// -----------------------------------------------------------------------------
+// per-device resources kept between calls (streams, events, grow-only buffers):
+// allocating and freeing device memory synchronises the whole device, so the
+// engine does it only when a call needs more than any earlier one
+// -----------------------------------------------------------------------------
+
+struct DeviceCache
+{
+    bool ready = false ;
+    hipStream_t sCompute = NULL, sCopy = NULL ;
+    hipEvent_t evStart = NULL, evStop = NULL ;
+    void *d_tasks = NULL, *d_refs = NULL, *d_vt = NULL, *h_stage = NULL ;
+    size_t cap_tasks = 0, cap_refs = 0, cap_vt = 0, cap_stage = 0 ;
+
+    hipError_t ensure (void **p, size_t *cap, size_t need, bool pinned_host)
+    {
+        if (need <= *cap) return hipSuccess ;
+        hipError_t e ;
+        if (*p) { e = pinned_host ? hipHostFree (*p) : hipFree (*p) ; *p = NULL ; *cap = 0 ; if (e != hipSuccess) return e ; }
+        size_t want = need + need / 4 ;
+        e = pinned_host ? hipHostMalloc (p, want, hipHostMallocDefault) : hipMalloc (p, want) ;
+        if (e != hipSuccess) { *p = NULL ; return e ; }
+        *cap = want ;
+        return hipSuccess ;
+    }
+    void release ( )
+    {
+        if (sCompute) (void) hipStreamDestroy (sCompute) ;
+        if (sCopy) (void) hipStreamDestroy (sCopy) ;
+        if (evStart) (void) hipEventDestroy (evStart) ;
+        if (evStop) (void) hipEventDestroy (evStop) ;
+        if (d_tasks) (void) hipFree (d_tasks) ;
+        if (d_refs) (void) hipFree (d_refs) ;
+        if (d_vt) (void) hipFree (d_vt) ;
+        if (h_stage) (void) hipHostFree (h_stage) ;
+        *this = DeviceCache ( ) ;
+    }
+} ;
+
+#define GPUQR_MAX_DEVICES 64
+static DeviceCache g_cache [GPUQR_MAX_DEVICES] ;
+
+static DeviceCache *device_cache (void)
+{
+    int dev = -1 ;
+    if (hipGetDevice (&dev) != hipSuccess || dev < 0 || dev >= GPUQR_MAX_DEVICES) return NULL ;
+    DeviceCache *dc = &g_cache [dev] ;
+    if (!dc->ready)
+    {
+        if (hipStreamCreateWithFlags (&dc->sCompute, hipStreamNonBlocking) != hipSuccess) { dc->release ( ) ; return NULL ; }
+        if (hipStreamCreateWithFlags (&dc->sCopy, hipStreamNonBlocking) != hipSuccess) { dc->release ( ) ; return NULL ; }
+        if (hipEventCreate (&dc->evStart) != hipSuccess) { dc->release ( ) ; return NULL ; }
+        if (hipEventCreate (&dc->evStop) != hipSuccess) { dc->release ( ) ; return NULL ; }
+        if (qr_kernels_init ( ) != hipSuccess) { dc->release ( ) ; return NULL ; }
+        dc->ready = true ;
+    }
+    return dc ;
+}
+
+extern "C" void gpuqr_finalize (void)
+{
+    int cur = -1 ;
+    (void) hipGetDevice (&cur) ;
+    for (int d = 0 ; d < GPUQR_MAX_DEVICES ; d++)
+    {
+        if (!g_cache [d].ready) continue ;
+        if (hipSetDevice (d) == hipSuccess) g_cache [d].release ( ) ;
+    }
+    if (cur >= 0) (void) hipSetDevice (cur) ;
+}
+
 static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
 {
     int code = GPUQR_SUCCESS ;
     QrTask *d_tasks = NULL ;
+    QrRef *d_refs = NULL ;
     double *d_vt = NULL ;
     hipStream_t sCompute = NULL, sCopy = NULL ;
     hipEvent_t evStart = NULL, evStop = NULL ;
-    hvec<hipEvent_t> evRound ;
+    DeviceCache *dc = NULL ;
+    hvec<hipEvent_t> evRound, evProf ;
+    hvec<int64_t> evProfBucket ;
     int64_t launches = 0 ;
     float ms = 0 ;
 
@@ -392,7 +494,9 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                         st.t.u.sasm.F = fr.gpuF ; st.t.u.sasm.S = fr.gpuS ;
                         st.t.u.sasm.pstart = ps ;
                         st.t.u.sasm.pend = std::min (ps + (int64_t) QR_SASM_CHUNK, fr.Scount) ;
-                        st.round = 0 ; st.vt = -1 ;
+                        st.round = 0 ; st.vt = -1 ; st.nblk = 1 ;
+                        st.flops = 0 ;
+                        st.bytes = 24.0 * (double) (st.t.u.sasm.pend - st.t.u.sasm.pstart) ;   // 16 read + 8 written
                         plan.tasks.push_back (st) ;
                     }
                 }
@@ -418,7 +522,15 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                         pk.cld = cld ; pk.pn = fr.pn ;
                         pk.cistart = ci ; pk.ciend = std::min (ci + QR_PACK_TILE, fr.cm) ;
                         pk.cjstart = cj ; pk.cjend = std::min (cj + QR_PACK_TILE, fr.cn) ;
-                        st.round = round ; st.vt = -1 ;
+                        st.round = round ; st.vt = -1 ; st.nblk = 1 ;
+                        {
+                            // entries of the tile on or above the diagonal: 8 read + 8 written, plus the map ints
+                            double cnt = 0 ;
+                            for (int32_t i = pk.cistart ; i < pk.ciend ; i++)
+                                cnt += (double) std::max (0, pk.cjend - std::max (pk.cjstart, i)) ;
+                            st.flops = 0 ;
+                            st.bytes = 16.0 * cnt + 4.0 * ((pk.ciend - pk.cistart) + (pk.cjend - pk.cjstart)) ;
+                        }
                         plan.tasks.push_back (st) ;
                     }
                 }
@@ -431,24 +543,43 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
         int32_t nrounds = 0 ;
         for (int64_t i = 0 ; i < ntasks ; i++) nrounds = std::max (nrounds, plan.tasks [i].round + 1) ;
 
-        // counting sort by (round, kernel id): one launch per non-empty bucket
+        // counting sort of the workgroups by (round, kernel id): one launch per non-empty bucket
         const int64_t nbuckets = (int64_t) nrounds * QR_NKERNELS ;
         hvec<int64_t> rptr ((size_t) nbuckets + 1, 0) ;
         for (int64_t i = 0 ; i < ntasks ; i++)
         {
             const SchedTask &st = plan.tasks [i] ;
-            rptr [(int64_t) st.round * QR_NKERNELS + qr_task_kernel_id (st.t.type, st.t.tier) + 1]++ ;
+            rptr [(int64_t) st.round * QR_NKERNELS + qr_task_kernel_id (st.t.type, st.t.tier) + 1] += st.nblk ;
         }
         for (int64_t b = 0 ; b < nbuckets ; b++) rptr [b+1] += rptr [b] ;
+        const int64_t nrefs = rptr [nbuckets] ;
+        hvec<double> bflops, bbytes ;
+        if (g_profile_on)
+        {
+            bflops.assign ((size_t) nbuckets, 0.0) ; bbytes.assign ((size_t) nbuckets, 0.0) ;
+            for (int64_t i = 0 ; i < ntasks ; i++)
+            {
+                const SchedTask &st = plan.tasks [i] ;
+                const int64_t b = (int64_t) st.round * QR_NKERNELS + qr_task_kernel_id (st.t.type, st.t.tier) ;
+                bflops [b] += st.flops ; bbytes [b] += st.bytes ;
+            }
+        }
 
-        if (hipStreamCreateWithFlags (&sCompute, hipStreamNonBlocking) != hipSuccess) { code = GPUQR_GPUERROR ; goto cleanup ; }
-        HIP_TRY (hipStreamCreateWithFlags (&sCopy, hipStreamNonBlocking)) ;
-        HIP_TRY (qr_kernels_init ( )) ;
+        dc = device_cache ( ) ;
+        if (!dc) { code = GPUQR_GPUERROR ; goto cleanup ; }
+        sCompute = dc->sCompute ; sCopy = dc->sCopy ; evStart = dc->evStart ; evStop = dc->evStop ;
 
         if (ntasks > 0)
         {
-            if (plan.n_vt > 0) HIP_TRY (hipMalloc ((void **) &d_vt, (size_t) plan.n_vt * QR_VT_DOUBLES * sizeof (double))) ;
-            hvec<QrTask> sorted ((size_t) ntasks) ;
+            const size_t task_bytes = (size_t) ntasks * sizeof (QrTask) ;
+            const size_t ref_bytes = (size_t) nrefs * sizeof (QrRef) ;
+            HIP_TRY (dc->ensure (&dc->d_vt, &dc->cap_vt, (size_t) plan.n_vt * QR_VT_DOUBLES * sizeof (double), false)) ;
+            HIP_TRY (dc->ensure (&dc->d_tasks, &dc->cap_tasks, task_bytes, false)) ;
+            HIP_TRY (dc->ensure (&dc->d_refs, &dc->cap_refs, ref_bytes, false)) ;
+            HIP_TRY (dc->ensure (&dc->h_stage, &dc->cap_stage, task_bytes + ref_bytes, true)) ;
+            d_vt = (double *) dc->d_vt ; d_tasks = (QrTask *) dc->d_tasks ; d_refs = (QrRef *) dc->d_refs ;
+            QrTask *h_tasks = (QrTask *) dc->h_stage ;
+            QrRef *h_refs = (QrRef *) ((char *) dc->h_stage + task_bytes) ;
             {
                 hvec<int64_t> pos (rptr) ;
                 for (int64_t i = 0 ; i < ntasks ; i++)
@@ -462,17 +593,19 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                         bool ok = pt.K >= 1 && pt.K <= QR_MAX_K && pt.w >= 1 && pt.w <= QR_PANEL_W
                             && pt.nseg >= 1 && pt.nseg <= QR_MAX_SEG && pt.col0 >= 0 && pt.col0 + pt.w <= pt.ld
                             && (st.t.type == QR_TASK_FACTORIZE || (pt.VT != NULL && pt.c_begin >= 0
-                                && pt.c_begin < pt.c_end && pt.c_end <= pt.ld)) ;
+                                && pt.c_begin < pt.c_end && pt.c_end <= pt.ld && pt.cb_cols >= 16
+                                && (int64_t) (st.nblk - 1) * pt.cb_cols < pt.c_end - pt.c_begin)) ;
                         int acc = 0 ;
                         for (int s = 0 ; s < pt.nseg && ok ; s++) { ok = pt.seg_row [s] >= 0 && pt.seg_n [s] >= 1 ; acc += pt.seg_n [s] ; }
                         if (!ok || acc != pt.K) { code = GPUQR_GPUERROR ; goto cleanup ; }
                     }
-                    sorted [pos [(int64_t) st.round * QR_NKERNELS + qr_task_kernel_id (st.t.type, st.t.tier)]++] = st.t ;
+                    h_tasks [i] = st.t ;
+                    int64_t &q = pos [(int64_t) st.round * QR_NKERNELS + qr_task_kernel_id (st.t.type, st.t.tier)] ;
+                    for (int32_t b = 0 ; b < st.nblk ; b++) { h_refs [q].task = (int32_t) i ; h_refs [q].blk = b ; q++ ; }
                 }
             }
-            HIP_TRY (hipMalloc ((void **) &d_tasks, (size_t) ntasks * sizeof (QrTask))) ;
-            HIP_TRY (hipMemcpyAsync (d_tasks, sorted.data ( ), (size_t) ntasks * sizeof (QrTask), hipMemcpyHostToDevice, sCompute)) ;
-            HIP_TRY (hipStreamSynchronize (sCompute)) ;      // 'sorted' may go out of scope below
+            HIP_TRY (hipMemcpyAsync (d_tasks, h_tasks, task_bytes, hipMemcpyHostToDevice, sCompute)) ;
+            HIP_TRY (hipMemcpyAsync (d_refs, h_refs, ref_bytes, hipMemcpyHostToDevice, sCompute)) ;
 
             // ---- fronts grouped by the round after which their data is final -------------
             hvec<int64_t> pull_order ;
@@ -484,8 +617,6 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                     return (ra != rb) ? (ra < rb) : (a < b) ;
                 }) ;
 
-            HIP_TRY (hipEventCreate (&evStart)) ;
-            HIP_TRY (hipEventCreate (&evStop)) ;
             HIP_TRY (hipEventRecord (evStart, sCompute)) ;
             size_t pi = 0 ;
             for (int32_t r = 0 ; r < nrounds ; r++)
@@ -496,7 +627,20 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                     const int64_t n = rptr [b+1] - rptr [b] ;
                     if (n > 0)
                     {
-                        HIP_TRY (qr_launch_tasks (kid, d_tasks + rptr [b], (int) n, sCompute)) ;
+                        if (g_profile_on)
+                        {
+                            hipEvent_t e0, e1 ;
+                            HIP_TRY (hipEventCreate (&e0)) ; evProf.push_back (e0) ;
+                            HIP_TRY (hipEventCreate (&e1)) ; evProf.push_back (e1) ;
+                            evProfBucket.push_back (b) ;
+                            HIP_TRY (hipEventRecord (e0, sCompute)) ;
+                            HIP_TRY (qr_launch_tasks (kid, d_tasks, d_refs + rptr [b], (int) n, sCompute)) ;
+                            HIP_TRY (hipEventRecord (e1, sCompute)) ;
+                        }
+                        else
+                        {
+                            HIP_TRY (qr_launch_tasks (kid, d_tasks, d_refs + rptr [b], (int) n, sCompute)) ;
+                        }
                         launches++ ;
                     }
                 }
@@ -522,6 +666,15 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
             HIP_TRY (hipStreamSynchronize (sCompute)) ;
             HIP_TRY (hipStreamSynchronize (sCopy)) ;
             HIP_TRY (hipEventElapsedTime (&ms, evStart, evStop)) ;
+            for (size_t i = 0 ; i < evProfBucket.size ( ) ; i++)
+            {
+                float t = 0 ;
+                HIP_TRY (hipEventElapsedTime (&t, evProf [2*i], evProf [2*i+1])) ;
+                const int64_t b = evProfBucket [i] ;
+                KernelProfile &kp = g_profile [b % QR_NKERNELS] ;
+                kp.ms += t ; kp.launches++ ; kp.tasks += rptr [b+1] - rptr [b] ;      // workgroups
+                kp.flops += bflops [b] ; kp.bytes += bbytes [b] ;
+            }
         }
         if (stats)
         {
@@ -539,12 +692,8 @@ cleanup:
     if (sCompute) (void) hipStreamSynchronize (sCompute) ;
     if (sCopy) (void) hipStreamSynchronize (sCopy) ;
     for (size_t i = 0 ; i < evRound.size ( ) ; i++) (void) hipEventDestroy (evRound [i]) ;
-    if (evStart) (void) hipEventDestroy (evStart) ;
-    if (evStop) (void) hipEventDestroy (evStop) ;
-    if (d_tasks) (void) hipFree (d_tasks) ;
-    if (d_vt) (void) hipFree (d_vt) ;
-    if (sCompute) (void) hipStreamDestroy (sCompute) ;
-    if (sCopy) (void) hipStreamDestroy (sCopy) ;
+    for (size_t i = 0 ; i < evProf.size ( ) ; i++) (void) hipEventDestroy (evProf [i]) ;
+    // streams, events and device buffers stay in the per-device cache for the next call
     return code ;
 }
 

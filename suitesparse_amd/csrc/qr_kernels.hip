@@ -267,7 +267,7 @@ __device__ void factorize_panel (const QrPanelTask &t, char *smem)
 #define VS_LD 34
 
 template <int MT>
-__device__ void apply_block (const QrPanelTask &t, char *smem)
+__device__ void apply_block (const QrPanelTask &t, const int blk, char *smem)
 {
     double (*Vs)[VS_LD] = reinterpret_cast<double (*)[VS_LD]>(smem) ;                       // [MT*16][34]
     double (*Ts)[VS_LD] = reinterpret_cast<double (*)[VS_LD]>(smem + (size_t) MT*16*VS_LD*8) ; // [32][34]
@@ -302,12 +302,14 @@ __device__ void apply_block (const QrPanelTask &t, char *smem)
 
     const int lane = tid & 63, wave = tid >> 6 ;
     const int lr = lane >> 4, lc = lane & 15 ;
-    const int nslab = (t.c_end - t.c_begin + 15) >> 4 ;
+    const int c_begin = t.c_begin + blk * t.cb_cols ;
+    const int c_end = (c_begin + t.cb_cols < t.c_end) ? (c_begin + t.cb_cols) : t.c_end ;
+    const int nslab = (c_end - c_begin + 15) >> 4 ;
 
     for (int slab = wave ; slab < nslab ; slab += 4)
     {
-        const int col = t.c_begin + slab*16 + lc ;
-        const bool cvalid = col < t.c_end ;
+        const int col = c_begin + slab*16 + lc ;
+        const bool cvalid = col < c_end ;
 
         v4f64 A [MT] ;
         #pragma unroll
@@ -439,23 +441,24 @@ __device__ void packassemble (const QrPackAssembleTask &t, char *smem)
 // -----------------------------------------------------------------------------
 
 template <int RPT>
-__global__ void __launch_bounds__ (QR_THREADS) k_factorize (const QrTask *tasks)
+__global__ void __launch_bounds__ (QR_THREADS) k_factorize (const QrTask *tasks, const QrRef *refs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem [] ;
-    factorize_panel<RPT> (tasks [blockIdx.x].u.panel, smem) ;
+    factorize_panel<RPT> (tasks [refs [blockIdx.x].task].u.panel, smem) ;
 }
 
 template <int MT>
-__global__ void __launch_bounds__ (QR_THREADS, 2) k_apply (const QrTask *tasks)
+__global__ void __launch_bounds__ (QR_THREADS, 2) k_apply (const QrTask *tasks, const QrRef *refs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem [] ;
-    apply_block<MT> (tasks [blockIdx.x].u.panel, smem) ;
+    const QrRef ref = refs [blockIdx.x] ;
+    apply_block<MT> (tasks [ref.task].u.panel, ref.blk, smem) ;
 }
 
-__global__ void __launch_bounds__ (QR_THREADS) k_assemble (const QrTask *tasks)
+__global__ void __launch_bounds__ (QR_THREADS) k_assemble (const QrTask *tasks, const QrRef *refs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem [] ;
-    const QrTask &t = tasks [blockIdx.x] ;
+    const QrTask &t = tasks [refs [blockIdx.x].task] ;
     if (t.type == QR_TASK_SASSEMBLE) sassemble (t.u.sasm) ;
     else                             packassemble (t.u.pack, smem) ;
 }
@@ -475,23 +478,23 @@ static size_t kernel_lds_bytes (int kid)
     return 2 * QR_PACK_TILE * sizeof (int) ;
 }
 
-// Launch ntasks consecutive tasks, all of kernel id kid, one workgroup each.
-extern "C" hipError_t qr_launch_tasks (int kid, const QrTask *d_tasks, int ntasks, hipStream_t stream)
+// Launch nrefs workgroups of kernel id kid: workgroup b runs (task, block) = d_refs [b].
+extern "C" hipError_t qr_launch_tasks (int kid, const QrTask *d_tasks, const QrRef *d_refs, int nrefs, hipStream_t stream)
 {
-    if (ntasks <= 0) return hipSuccess ;
-    const dim3 grid (ntasks), block (QR_THREADS) ;
+    if (nrefs <= 0) return hipSuccess ;
+    const dim3 grid (nrefs), block (QR_THREADS) ;
     const size_t lds = kernel_lds_bytes (kid) ;
     switch (kid)
     {
-        case 0: hipLaunchKernelGGL (k_factorize<4>,  grid, block, lds, stream, d_tasks) ; break ;
-        case 1: hipLaunchKernelGGL (k_factorize<8>,  grid, block, lds, stream, d_tasks) ; break ;
-        case 2: hipLaunchKernelGGL (k_factorize<16>, grid, block, lds, stream, d_tasks) ; break ;
-        case 3: hipLaunchKernelGGL (k_factorize<32>, grid, block, lds, stream, d_tasks) ; break ;
-        case 4: hipLaunchKernelGGL (k_apply<2>,      grid, block, lds, stream, d_tasks) ; break ;
-        case 5: hipLaunchKernelGGL (k_apply<4>,      grid, block, lds, stream, d_tasks) ; break ;
-        case 6: hipLaunchKernelGGL (k_apply<8>,      grid, block, lds, stream, d_tasks) ; break ;
-        case 7: hipLaunchKernelGGL (k_apply<16>,     grid, block, lds, stream, d_tasks) ; break ;
-        case 8: hipLaunchKernelGGL (k_assemble,      grid, block, lds, stream, d_tasks) ; break ;
+        case 0: hipLaunchKernelGGL (k_factorize<4>,  grid, block, lds, stream, d_tasks, d_refs) ; break ;
+        case 1: hipLaunchKernelGGL (k_factorize<8>,  grid, block, lds, stream, d_tasks, d_refs) ; break ;
+        case 2: hipLaunchKernelGGL (k_factorize<16>, grid, block, lds, stream, d_tasks, d_refs) ; break ;
+        case 3: hipLaunchKernelGGL (k_factorize<32>, grid, block, lds, stream, d_tasks, d_refs) ; break ;
+        case 4: hipLaunchKernelGGL (k_apply<2>,      grid, block, lds, stream, d_tasks, d_refs) ; break ;
+        case 5: hipLaunchKernelGGL (k_apply<4>,      grid, block, lds, stream, d_tasks, d_refs) ; break ;
+        case 6: hipLaunchKernelGGL (k_apply<8>,      grid, block, lds, stream, d_tasks, d_refs) ; break ;
+        case 7: hipLaunchKernelGGL (k_apply<16>,     grid, block, lds, stream, d_tasks, d_refs) ; break ;
+        case 8: hipLaunchKernelGGL (k_assemble,      grid, block, lds, stream, d_tasks, d_refs) ; break ;
         default: return hipErrorInvalidValue ;
     }
     return hipGetLastError ( ) ;

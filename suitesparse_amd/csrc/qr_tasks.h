@@ -43,7 +43,8 @@ struct QrPanelTask
     int32_t  w;                 // panel width (1..32)
     int32_t  K;                 // rows gathered (1..256)
     int32_t  nseg;
-    int32_t  c_begin, c_end;    // apply only: column range updated
+    int32_t  c_begin, c_end;    // apply only: column range updated by the whole group of workgroups
+    int32_t  cb_cols;           // apply only: columns per workgroup (block blk covers c_begin + blk*cb_cols ...)
     int32_t  seg_row [QR_MAX_SEG];
     int32_t  seg_n   [QR_MAX_SEG];
 };
@@ -64,6 +65,13 @@ struct QrPackAssembleTask
     int32_t       cld;          // leading dimension of C (child fn, or cn for push-only fronts)
     int32_t       pn;
     int32_t       cistart, ciend, cjstart, cjend;
+};
+
+// One workgroup = one (task, block) pair; only apply tasks have more than one block.
+struct QrRef
+{
+    int32_t task;               // index into the task array of the call
+    int32_t blk;                // column block within an apply task, else 0
 };
 
 struct QrTask
