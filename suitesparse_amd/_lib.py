@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgpuqrengine_amd.so")
+LIB_PATH = os.environ.get("GPUQR_LIB_PATH") or os.path.join(_HERE, "lib", "libgpuqrengine_amd.so")
 
 GPUQR_SUCCESS, GPUQR_OUTOFMEMORY, GPUQR_GPUERROR = 0, 1, 2
 

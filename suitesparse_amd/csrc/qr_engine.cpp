@@ -132,6 +132,9 @@ struct SchedTask
 // optional per-kernel profile (HIP events around every launch)
 // -----------------------------------------------------------------------------
 
+static int g_stagger = 1 ;     // start rounds of childless fronts are spread over this many rounds
+extern "C" void gpuqr_set_stagger (int rounds) { g_stagger = rounds ; }
+
 struct KernelProfile { double ms, flops, bytes ; int64_t launches, tasks ; } ;
 static int g_profile_on = 0 ;
 static KernelProfile g_profile [QR_NKERNELS] ;
@@ -358,8 +361,9 @@ extern "C" int64_t gpuqr_front_flops (int64_t fm, int64_t fn, const int64_t *Sta
 struct DeviceCache
 {
     bool ready = false ;
-    hipStream_t sCompute = NULL, sCopy = NULL ;
+    hipStream_t sCompute = NULL, sApply = NULL, sCopy = NULL ;
     hipEvent_t evStart = NULL, evStop = NULL ;
+    std::vector<hipEvent_t> evPool ;        // untimed events, reused by every call
     void *d_tasks = NULL, *d_refs = NULL, *d_vt = NULL, *h_stage = NULL ;
     size_t cap_tasks = 0, cap_refs = 0, cap_vt = 0, cap_stage = 0 ;
 
@@ -374,10 +378,23 @@ struct DeviceCache
         *cap = want ;
         return hipSuccess ;
     }
+    // k-th untimed event of the pool (created on first use)
+    hipEvent_t pooled_event (size_t k)
+    {
+        while (evPool.size ( ) <= k)
+        {
+            hipEvent_t ev = NULL ;
+            if (hipEventCreateWithFlags (&ev, hipEventDisableTiming) != hipSuccess) return NULL ;
+            evPool.push_back (ev) ;
+        }
+        return evPool [k] ;
+    }
     void release ( )
     {
         if (sCompute) (void) hipStreamDestroy (sCompute) ;
+        if (sApply) (void) hipStreamDestroy (sApply) ;
         if (sCopy) (void) hipStreamDestroy (sCopy) ;
+        for (size_t i = 0 ; i < evPool.size ( ) ; i++) (void) hipEventDestroy (evPool [i]) ;
         if (evStart) (void) hipEventDestroy (evStart) ;
         if (evStop) (void) hipEventDestroy (evStop) ;
         if (d_tasks) (void) hipFree (d_tasks) ;
@@ -398,7 +415,12 @@ static DeviceCache *device_cache (void)
     DeviceCache *dc = &g_cache [dev] ;
     if (!dc->ready)
     {
-        if (hipStreamCreateWithFlags (&dc->sCompute, hipStreamNonBlocking) != hipSuccess) { dc->release ( ) ; return NULL ; }
+        // the panel stream gets the highest priority: its few long workgroups then take the
+        // compute-unit slots that free up first instead of queueing behind thousands of updates
+        int prio_lo = 0, prio_hi = 0 ;
+        if (hipDeviceGetStreamPriorityRange (&prio_lo, &prio_hi) != hipSuccess) { prio_lo = prio_hi = 0 ; }
+        if (hipStreamCreateWithPriority (&dc->sCompute, hipStreamNonBlocking, prio_hi) != hipSuccess) { dc->release ( ) ; return NULL ; }
+        if (hipStreamCreateWithPriority (&dc->sApply, hipStreamNonBlocking, prio_lo) != hipSuccess) { dc->release ( ) ; return NULL ; }
         if (hipStreamCreateWithFlags (&dc->sCopy, hipStreamNonBlocking) != hipSuccess) { dc->release ( ) ; return NULL ; }
         if (hipEventCreate (&dc->evStart) != hipSuccess) { dc->release ( ) ; return NULL ; }
         if (hipEventCreate (&dc->evStop) != hipSuccess) { dc->release ( ) ; return NULL ; }
@@ -426,10 +448,10 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
     QrTask *d_tasks = NULL ;
     QrRef *d_refs = NULL ;
     double *d_vt = NULL ;
-    hipStream_t sCompute = NULL, sCopy = NULL ;
+    hipStream_t sCompute = NULL, sApply = NULL, sCopy = NULL ;
     hipEvent_t evStart = NULL, evStop = NULL ;
     DeviceCache *dc = NULL ;
-    hvec<hipEvent_t> evRound, evProf ;
+    hvec<hipEvent_t> evProf ;
     hvec<int64_t> evProfBucket ;
     int64_t launches = 0 ;
     float ms = 0 ;
@@ -476,6 +498,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
 
         // ---- build the schedule -----------------------------------------------------
         Plan plan ;
+        int64_t nleaf = 0 ;
         hvec<int32_t> done_round ((size_t) nf, 0) ;
         for (size_t k = 0 ; k < order.size ( ) ; k++)
         {
@@ -501,6 +524,10 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                     }
                 }
                 int32_t start = std::max (1, child_pack_round [f] + 1) ;
+                // fronts with no children would all start in round 1 and march in lockstep, every
+                // panel round of one coinciding with the panel rounds of the others; shifting their
+                // starts over a few rounds lets one front's updates overlap another's panels
+                if (child_pack_round [f] == 0 && g_stagger > 1) start += (int32_t) ((nleaf++) % g_stagger) ;
                 done = plan_front (plan, fr.gpuF, fr.fm, fr.fn, fr.Stair, start, true) ;
                 if (done < start - 1) done = start - 1 ;
             }
@@ -567,7 +594,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
 
         dc = device_cache ( ) ;
         if (!dc) { code = GPUQR_GPUERROR ; goto cleanup ; }
-        sCompute = dc->sCompute ; sCopy = dc->sCopy ; evStart = dc->evStart ; evStop = dc->evStop ;
+        sCompute = dc->sCompute ; sApply = dc->sApply ; sCopy = dc->sCopy ; evStart = dc->evStart ; evStop = dc->evStop ;
 
         if (ntasks > 0)
         {
@@ -617,40 +644,61 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                     return (ra != rb) ? (ra < rb) : (a < b) ;
                 }) ;
 
+            // Two compute streams: factorize kernels on one, apply and assembly kernels on the
+            // other, so that the latency-bound panel tasks of a round overlap its bandwidth-bound
+            // updates.  Round r on either stream waits for round r-1 on the other.
             HIP_TRY (hipEventRecord (evStart, sCompute)) ;
-            size_t pi = 0 ;
+            HIP_TRY (hipStreamWaitEvent (sApply, evStart, 0)) ;        // the task upload
+            size_t pi = 0, nev = 0 ;
+            hipEvent_t prevF = NULL, prevA = NULL ;
             for (int32_t r = 0 ; r < nrounds ; r++)
             {
+                bool hasF = false, hasA = false ;
+                for (int kid = 0 ; kid < QR_NKERNELS ; kid++)
+                {
+                    const int64_t b = (int64_t) r * QR_NKERNELS + kid ;
+                    if (rptr [b+1] > rptr [b]) { if (kid < 4) hasF = true ; else hasA = true ; }
+                }
+                if (hasF && prevA) HIP_TRY (hipStreamWaitEvent (sCompute, prevA, 0)) ;
+                if (hasA && prevF) HIP_TRY (hipStreamWaitEvent (sApply, prevF, 0)) ;
                 for (int kid = 0 ; kid < QR_NKERNELS ; kid++)
                 {
                     const int64_t b = (int64_t) r * QR_NKERNELS + kid ;
                     const int64_t n = rptr [b+1] - rptr [b] ;
-                    if (n > 0)
+                    if (n <= 0) continue ;
+                    hipStream_t st = (kid < 4) ? sCompute : sApply ;
+                    if (g_profile_on)
                     {
-                        if (g_profile_on)
-                        {
-                            hipEvent_t e0, e1 ;
-                            HIP_TRY (hipEventCreate (&e0)) ; evProf.push_back (e0) ;
-                            HIP_TRY (hipEventCreate (&e1)) ; evProf.push_back (e1) ;
-                            evProfBucket.push_back (b) ;
-                            HIP_TRY (hipEventRecord (e0, sCompute)) ;
-                            HIP_TRY (qr_launch_tasks (kid, d_tasks, d_refs + rptr [b], (int) n, sCompute)) ;
-                            HIP_TRY (hipEventRecord (e1, sCompute)) ;
-                        }
-                        else
-                        {
-                            HIP_TRY (qr_launch_tasks (kid, d_tasks, d_refs + rptr [b], (int) n, sCompute)) ;
-                        }
-                        launches++ ;
+                        hipEvent_t e0, e1 ;
+                        HIP_TRY (hipEventCreate (&e0)) ; evProf.push_back (e0) ;
+                        HIP_TRY (hipEventCreate (&e1)) ; evProf.push_back (e1) ;
+                        evProfBucket.push_back (b) ;
+                        HIP_TRY (hipEventRecord (e0, st)) ;
+                        HIP_TRY (qr_launch_tasks (kid, d_tasks, d_refs + rptr [b], (int) n, st)) ;
+                        HIP_TRY (hipEventRecord (e1, st)) ;
                     }
+                    else
+                    {
+                        HIP_TRY (qr_launch_tasks (kid, d_tasks, d_refs + rptr [b], (int) n, st)) ;
+                    }
+                    launches++ ;
+                }
+                if (hasF)
+                {
+                    prevF = dc->pooled_event (nev++) ;
+                    if (!prevF) { code = GPUQR_GPUERROR ; goto cleanup ; }
+                    HIP_TRY (hipEventRecord (prevF, sCompute)) ;
+                }
+                if (hasA)
+                {
+                    prevA = dc->pooled_event (nev++) ;
+                    if (!prevA) { code = GPUQR_GPUERROR ; goto cleanup ; }
+                    HIP_TRY (hipEventRecord (prevA, sApply)) ;
                 }
                 if (pi < pull_order.size ( ) && std::min (done_round [pull_order [pi]], nrounds - 1) <= r)
                 {
-                    hipEvent_t ev ;
-                    HIP_TRY (hipEventCreateWithFlags (&ev, hipEventDisableTiming)) ;
-                    evRound.push_back (ev) ;
-                    HIP_TRY (hipEventRecord (ev, sCompute)) ;
-                    HIP_TRY (hipStreamWaitEvent (sCopy, ev, 0)) ;
+                    if (prevF) HIP_TRY (hipStreamWaitEvent (sCopy, prevF, 0)) ;
+                    if (prevA) HIP_TRY (hipStreamWaitEvent (sCopy, prevA, 0)) ;
                     while (pi < pull_order.size ( ) && std::min (done_round [pull_order [pi]], nrounds - 1) <= r)
                     {
                         gpuqr_front &fr = fronts [pull_order [pi++]] ;
@@ -662,8 +710,10 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                     }
                 }
             }
+            if (prevA) HIP_TRY (hipStreamWaitEvent (sCompute, prevA, 0)) ;
             HIP_TRY (hipEventRecord (evStop, sCompute)) ;
             HIP_TRY (hipStreamSynchronize (sCompute)) ;
+            HIP_TRY (hipStreamSynchronize (sApply)) ;
             HIP_TRY (hipStreamSynchronize (sCopy)) ;
             HIP_TRY (hipEventElapsedTime (&ms, evStart, evStop)) ;
             for (size_t i = 0 ; i < evProfBucket.size ( ) ; i++)
@@ -690,8 +740,8 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
 
 cleanup:
     if (sCompute) (void) hipStreamSynchronize (sCompute) ;
+    if (sApply) (void) hipStreamSynchronize (sApply) ;
     if (sCopy) (void) hipStreamSynchronize (sCopy) ;
-    for (size_t i = 0 ; i < evRound.size ( ) ; i++) (void) hipEventDestroy (evRound [i]) ;
     for (size_t i = 0 ; i < evProf.size ( ) ; i++) (void) hipEventDestroy (evProf [i]) ;
     // streams, events and device buffers stay in the per-device cache for the next call
     return code ;

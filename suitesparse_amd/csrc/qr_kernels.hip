@@ -306,12 +306,14 @@ __device__ void apply_block (const QrPanelTask &t, const int blk, char *smem)
     const int c_end = (c_begin + t.cb_cols < t.c_end) ? (c_begin + t.cb_cols) : t.c_end ;
     const int nslab = (c_end - c_begin + 15) >> 4 ;
 
-    for (int slab = wave ; slab < nslab ; slab += 4)
+    // Software pipeline over the wave's slabs: while step 3 finishes tile mt of
+    // the current slab, that tile is stored and the same registers are refilled
+    // with tile mt of the wave's next slab, so the loads and stores of one slab
+    // travel while the matrix pipe works on another.
+    v4f64 A [MT] ;
     {
-        const int col = c_begin + slab*16 + lc ;
-        const bool cvalid = col < c_end ;
-
-        v4f64 A [MT] ;
+        const int col = c_begin + wave*16 + lc ;
+        const bool cvalid = (wave < nslab) && (col < c_end) ;
         #pragma unroll
         for (int mt = 0 ; mt < MT ; mt++)
         {
@@ -319,9 +321,21 @@ __device__ void apply_block (const QrPanelTask &t, const int blk, char *smem)
             for (int i = 0 ; i < 4 ; i++)
             {
                 int r = mt*16 + 4*i + lr ;
+#ifdef ABL_NOMEM
+                A [mt][i] = (double) (r + col) ;
+#else
                 A [mt][i] = (cvalid && r < K) ? F [(size_t) rowmap [r] * ld + col] : 0.0 ;
+#endif
             }
         }
+    }
+
+    for (int slab = wave ; slab < nslab ; slab += 4)
+    {
+        const int col = c_begin + slab*16 + lc ;
+        const bool cvalid = col < c_end ;
+        const int ncol = col + 64 ;
+        const bool nvalid = (slab + 4 < nslab) && (ncol < c_end) ;
 
         // step 1: W = V' A, two 16-row tiles of W, two accumulators each
         v4f64 W0a = {0,0,0,0}, W1a = {0,0,0,0}, W0b = {0,0,0,0}, W1b = {0,0,0,0} ;
@@ -362,7 +376,12 @@ __device__ void apply_block (const QrPanelTask &t, const int blk, char *smem)
         }
         X0 = -X0 ; X1 = -X1 ;
 
-        // step 3: A += V (-X)
+        // step 3: A += V (-X), tile by tile; store the tile, fetch its successor.
+        // The opaque copy of the lane row makes the compiler recompute the
+        // addresses from the row map instead of keeping 64 address pairs alive
+        // across the MFMA section.
+        int lr_st = lr ;
+        asm volatile ("" : "+v" (lr_st)) ;
         #pragma unroll
         for (int mt = 0 ; mt < MT ; mt++)
         {
@@ -373,22 +392,25 @@ __device__ void apply_block (const QrPanelTask &t, const int blk, char *smem)
             #pragma unroll
             for (int q = 0 ; q < 4 ; q++)
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [mt*16 + lc][16 + 4*q + lr], X1 [q], acc, 0, 0, 0) ;
-            A [mt] = acc ;
-        }
-
-        // Recompute the store addresses from the row map instead of keeping
-        // 64 address pairs alive across the MFMA section: the opaque copy of
-        // the lane row stops the compiler from reusing the load addresses.
-        int lr_st = lr ;
-        asm volatile ("" : "+v" (lr_st)) ;
-        #pragma unroll
-        for (int mt = 0 ; mt < MT ; mt++)
-        {
             #pragma unroll
             for (int i = 0 ; i < 4 ; i++)
             {
                 int r = mt*16 + 4*i + lr_st ;
-                if (cvalid && r < K) F [(size_t) rowmap [r] * ld + col] = A [mt][i] ;
+                if (r < K)
+                {
+                    double *rowp = F + (size_t) rowmap [r] * ld ;
+#ifdef ABL_NOMEM
+                    if (acc [i] == 1.2345e-300) rowp [col] = acc [i] ;
+                    A [mt][i] = acc [i] + 1.0 ;
+#else
+                    if (cvalid) rowp [col] = acc [i] ;
+                    A [mt][i] = nvalid ? rowp [ncol] : 0.0 ;
+#endif
+                }
+                else
+                {
+                    A [mt][i] = 0.0 ;
+                }
             }
         }
     }
