@@ -96,6 +96,8 @@ typedef struct spqr_amd_numeric
     int64_t  gpuFlops, gpuNumKernelLaunches;
     int64_t  numStagesRun;
     double   assembleBytes; /* algorithmic bytes moved by S- and pack-assembly */
+    double  *Cstack;        /* subset driver: contribution blocks leaving this process (compact cm-by-cn) */
+    int64_t *Cblock;        /* subset driver: size nf, offset of front f's block in Cstack or -1 */
 } spqr_amd_numeric;
 
 /* Replaces void spqrgpu_kernel (spqr_blob <double> *Blob)
@@ -113,6 +115,22 @@ void spqr_amd_numeric_free (spqr_amd_numeric *num);
  * with Rp only (size n+1) to get the counts, then with Ri/Rx of size Rp[n]. */
 int spqr_amd_rconvert (const spqr_amd_symbolic *sym, const spqr_amd_numeric *num,
                        int64_t *Rp, int64_t *Ri, double *Rx);
+
+/* The same conversion on raw arrays, for R blocks gathered from several processes:
+ * Rblock[f] < 0 marks a front whose block is absent (it still consumes its rows). */
+int spqr_amd_rconvert_blocks (const spqr_amd_symbolic *sym, const double *Rstack, const int64_t *Rblock,
+                              const char *Rdead, int64_t *Rp, int64_t *Ri, double *Rx);
+
+/* One process's share of the assembly tree (no counterpart in the single-GPU reference; it
+ * generalises its stage / limbo hand-off, spqrgpu_kernel.cpp:556-611,687-724, from "a later stage"
+ * to "another GPU").  Fronts with mine[f] != 0 are factorized in one stage on the current device.
+ * limbo_in[c] (host, compact cm-by-cn, may be NULL where unused) supplies the contribution block
+ * of every child c of those fronts that another process factorized; fronts whose parent belongs
+ * to another process leave their block in num->Cstack at num->Cblock[f].  Rblock[f] = -1 for
+ * fronts not factorized here. */
+int spqrgpu_amd_factorize_subset (const spqr_amd_symbolic *sym, const int64_t *Ap, const int64_t *Ai,
+                                  const double *Ax, const char *mine, const double *const *limbo_in,
+                                  spqr_amd_numeric **num_out);
 
 #ifdef __cplusplus
 }

@@ -189,7 +189,7 @@ extern "C" void spqrgpu_amd_build_assembly_maps
 extern "C" void spqr_amd_numeric_free (spqr_amd_numeric *num)
 {
     if (!num) return ;
-    free (num->Rstack) ; free (num->Rblock) ; free (num->Rdead) ;
+    free (num->Rstack) ; free (num->Rblock) ; free (num->Rdead) ; free (num->Cstack) ; free (num->Cblock) ;
     free (num) ;
 }
 
@@ -426,13 +426,16 @@ done:
 }
 
 // R blocks -> compressed-column R (the R-only part of spqr_rcount / spqr_rconvert,
-// SPQR/Source/spqr_rconvert.cpp:127-260 with keepH = false, n1rows = 0)
-extern "C" int spqr_amd_rconvert
+// SPQR/Source/spqr_rconvert.cpp:127-260 with keepH = false, n1rows = 0).  Fronts whose
+// Rblock offset is negative (factorized by another process) contribute their rows as
+// structural positions with no values only if skip_missing is 0; with it they are left out.
+extern "C" int spqr_amd_rconvert_blocks
 (
-    const spqr_amd_symbolic *S, const spqr_amd_numeric *num, int64_t *Rcp, int64_t *Ri, double *Rx
+    const spqr_amd_symbolic *S, const double *Rstack, const int64_t *Rblock, const char *Rdead,
+    int64_t *Rcp, int64_t *Ri, double *Rx
 )
 {
-    if (!S || !num || !Rcp) return 3 ;
+    if (!S || !Rstack || !Rblock || !Rdead || !Rcp) return 3 ;
     const Long nf = S->nf, n = S->n ;
     const bool fill = (Ri != NULL && Rx != NULL) ;
     std::vector<Long> next ;
@@ -441,15 +444,16 @@ extern "C" int spqr_amd_rconvert
     Long row1 = 0 ;
     for (Long f = 0 ; f < nf ; f++)
     {
-        const double *R = num->Rstack + num->Rblock [f] ;
+        const double *R = (Rblock [f] >= 0) ? Rstack + Rblock [f] : NULL ;
         const Long col1 = S->Super [f], fp = S->Super [f+1] - col1 ;
         const Long pr = S->Rp [f], fn = S->Rp [f+1] - pr ;
         Long rm = 0 ;
         for (Long k = 0 ; k < fn ; k++)
         {
             Long j ;
-            if (k < fp) { j = col1 + k ; if (!num->Rdead [j]) rm++ ; }
+            if (k < fp) { j = col1 + k ; if (!Rdead [j]) rm++ ; }
             else j = S->Rj [pr + k] ;
+            if (!R) continue ;
             for (Long i = 0 ; i < rm ; i++)
             {
                 const double x = *R++ ;
@@ -460,5 +464,246 @@ extern "C" int spqr_amd_rconvert
         row1 += rm ;
     }
     if (!fill) for (Long j = 0 ; j < n ; j++) Rcp [j+1] += Rcp [j] ;
+    return 0 ;
+}
+
+extern "C" int spqr_amd_rconvert
+(
+    const spqr_amd_symbolic *S, const spqr_amd_numeric *num, int64_t *Rcp, int64_t *Ri, double *Rx
+)
+{
+    if (!num) return 3 ;
+    return spqr_amd_rconvert_blocks (S, num->Rstack, num->Rblock, num->Rdead, Rcp, Ri, Rx) ;
+}
+
+// -----------------------------------------------------------------------------
+// subtree driver: one process's share of the assembly tree
+// -----------------------------------------------------------------------------
+
+// Factorize the fronts f with mine[f] != 0 in one stage on the current device.
+// Children of those fronts that belong to somebody else arrive as compact
+// cm-by-cn contribution blocks in limbo_in[c] (host); fronts whose parent
+// belongs to somebody else leave theirs in num->Cstack at Cblock[f].  This is
+// the reference's stage / limbo mechanism (spqrgpu_kernel.cpp:556-611,687-724)
+// with "a later stage" generalised to "another process".
+extern "C" int spqrgpu_amd_factorize_subset
+(
+    const spqr_amd_symbolic *S, const int64_t *Ap, const int64_t *Ai, const double *Ax,
+    const char *mine, const double *const *limbo_in, spqr_amd_numeric **num_out
+)
+{
+    if (!S || !Ap || !Ax || !mine || !num_out) return 3 ;
+    *num_out = NULL ;
+    int code = 0 ;
+    const Long nf = S->nf, n = S->n, m = S->m ;
+    const Long *Super = S->Super.data ( ), *Rp = S->Rp.data ( ), *Post = S->Post.data ( ) ;
+    const Long *Parent = S->Parent.data ( ), *Childp = S->Childp.data ( ), *Child = S->Child.data ( ) ;
+    const Long *Fm = S->Fm.data ( ), *Cm = S->Cm.data ( ), *Sleft = S->Sleft.data ( ), *Sp = S->Sp.data ( ) ;
+
+    spqr_amd_numeric *num = (spqr_amd_numeric *) calloc (1, sizeof (spqr_amd_numeric)) ;
+    if (!num) return 1 ;
+    double *dF = NULL ; gpuqr_sentry *dS = NULL ; int32_t *dRimap = NULL, *dRjmap = NULL ;
+    double *hR = NULL ; gpuqr_sentry *hS = NULL ;
+    gpuqr_front *fronts = NULL ;
+
+    try
+    {
+        // ---- layout of this process's arena -----------------------------------------------
+        std::vector<Long> rel (nf, -1), FOff (nf, 0), ROff (nf, 0), SOff (nf, 0), SGlob (nf + 1, 0) ;
+        Long nmine = 0, nlimbo = 0 ;
+        size_t fsum = 0, rsum = 0, ssum = 0, rpack = 0, cpack = 0 ;
+        {
+            Long sacc = 0 ;
+            for (Long k = 0 ; k < nf ; k++)          // packed S is laid out front after front in postorder
+            {
+                const Long f = Post [k] ;
+                SGlob [f] = sacc ;
+                sacc += std::max ((Long) 0, Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]]) ;
+            }
+        }
+        for (Long k = 0 ; k < nf ; k++)
+        {
+            const Long f = Post [k] ;
+            if (!mine [f]) continue ;
+            const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
+            const Long frank = std::min (fm, fp) ;
+            rel [f] = nmine++ ;
+            FOff [f] = (Long) fsum ; ROff [f] = (Long) rsum ; SOff [f] = (Long) ssum ;
+            fsum += (size_t) (fm * fn) ;
+            for (Long cp = Childp [f] ; cp < Childp [f+1] ; cp++)
+            {
+                const Long c = Child [cp] ;
+                if (mine [c]) continue ;
+                nlimbo++ ;
+                fsum += (size_t) (Cm [c] * ((Rp [c+1] - Rp [c]) - (Super [c+1] - Super [c]))) ;
+            }
+            rsum += (size_t) ((frank + Cm [f]) * fn) ;
+            ssum += (size_t) std::max ((Long) 0, Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]]) ;
+            rpack += (size_t) (frank*(frank+1)/2 + frank*(fn-frank)) ;
+            if (Parent [f] < nf && !mine [Parent [f]]) cpack += (size_t) (Cm [f] * (fn - fp)) ;
+        }
+
+        num->nf = nf ;
+        num->rsize = (Long) rpack ;
+        num->Rstack = (double *) malloc (std::max ((size_t) 1, rpack) * sizeof (double)) ;
+        num->Rblock = (Long *) malloc (std::max ((Long) 1, nf) * sizeof (Long)) ;
+        num->Rdead = (char *) calloc (std::max ((Long) 1, n), 1) ;
+        num->Cstack = (double *) calloc (std::max ((size_t) 1, cpack), sizeof (double)) ;
+        num->Cblock = (Long *) malloc (std::max ((Long) 1, nf) * sizeof (Long)) ;
+        if (!num->Rstack || !num->Rblock || !num->Rdead || !num->Cstack || !num->Cblock) { code = 1 ; goto done ; }
+        for (Long f = 0 ; f < nf ; f++) { num->Rblock [f] = -1 ; num->Cblock [f] = -1 ; }
+
+        // ---- S values, maps, packed S (whole problem: pattern work only) ---------------------
+        std::vector<double> Sx ((size_t) S->anz) ;
+        {
+            std::vector<Long> w (Sp, Sp + m) ;
+            for (Long k = 0 ; k < n ; k++)
+            {
+                const Long col = S->Qfill [k] ;
+                for (Long p = Ap [col] ; p < Ap [col+1] ; p++) Sx [w [S->PLinv [Ai [p]]]++] = Ax [p] ;
+            }
+        }
+        const Long RimapSize = std::max ((Long) 1, S->RimapSize), RjmapSize = std::max ((Long) 1, S->RjmapSize) ;
+        std::vector<Long> Stair ((size_t) std::max ((Long) 1, Rp [nf])), Fmap ((size_t) std::max ((Long) 1, n)) ;
+        std::vector<int32_t> Rimap ((size_t) RimapSize), Rjmap ((size_t) RjmapSize) ;
+        std::vector<gpuqr_sentry> allS ((size_t) std::max ((Long) 1, S->anz)) ;
+        spqrgpu_amd_build_assembly_maps (nf, n, Fmap.data ( ), Post, Super, Rp, S->Rj.data ( ), Sleft, Sp,
+            S->Sj.data ( ), Sx.data ( ), Fm, Cm, Childp, Child, Stair.data ( ), Rjmap.data ( ),
+            S->RjmapOffsets.data ( ), Rimap.data ( ), S->RimapOffsets.data ( ), allS.data ( )) ;
+
+        if (nmine > 0)
+        {
+            if (hipHostMalloc ((void **) &hS, std::max ((size_t) 1, ssum) * sizeof (gpuqr_sentry), hipHostMallocDefault) != hipSuccess) { hS = NULL ; code = 1 ; goto done ; }
+            for (Long f = 0 ; f < nf ; f++)
+            {
+                if (!mine [f]) continue ;
+                const Long cnt = std::max ((Long) 0, Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]]) ;
+                if (cnt > 0) memcpy (hS + SOff [f], allS.data ( ) + SGlob [f], (size_t) cnt * sizeof (gpuqr_sentry)) ;
+            }
+            if (hipMalloc ((void **) &dRimap, RimapSize * sizeof (int32_t)) != hipSuccess) { dRimap = NULL ; code = 1 ; goto done ; }
+            if (hipMalloc ((void **) &dRjmap, RjmapSize * sizeof (int32_t)) != hipSuccess) { dRjmap = NULL ; code = 1 ; goto done ; }
+            HIPCHK (hipMemcpy (dRimap, Rimap.data ( ), RimapSize * sizeof (int32_t), hipMemcpyHostToDevice)) ;
+            HIPCHK (hipMemcpy (dRjmap, Rjmap.data ( ), RjmapSize * sizeof (int32_t), hipMemcpyHostToDevice)) ;
+            if (hipMalloc ((void **) &dF, std::max ((size_t) 1, fsum) * sizeof (double)) != hipSuccess) { dF = NULL ; code = 1 ; goto done ; }
+            if (hipMalloc ((void **) &dS, std::max ((size_t) 1, ssum) * sizeof (gpuqr_sentry)) != hipSuccess) { dS = NULL ; code = 1 ; goto done ; }
+            if (hipHostMalloc ((void **) &hR, std::max ((size_t) 1, rsum) * sizeof (double), hipHostMallocDefault) != hipSuccess) { hR = NULL ; code = 1 ; goto done ; }
+            fronts = (gpuqr_front *) malloc ((size_t) (nmine + nlimbo) * sizeof (gpuqr_front)) ;
+            if (!fronts) { code = 1 ; goto done ; }
+            HIPCHK (hipMemset (dF, 0, std::max ((size_t) 1, fsum) * sizeof (double))) ;
+            if (ssum > 0) HIPCHK (hipMemcpy (dS, hS, ssum * sizeof (gpuqr_sentry), hipMemcpyHostToDevice)) ;
+
+            Long next_child = nmine ;
+            for (Long f = 0 ; f < nf ; f++)
+            {
+                if (!mine [f]) continue ;
+                const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
+                const Long frank = std::min (fm, fp) ;
+                const Long pid = Parent [f] ;
+                const bool parent_mine = (pid < nf && mine [pid]) ;
+                gpuqr_front &fr = fronts [rel [f]] ;
+                memset (&fr, 0, sizeof (fr)) ;
+                fr.fids = rel [f] ; fr.pids = parent_mine ? rel [pid] : -1 ; fr.fidg = f ; fr.pidg = pid ;
+                fr.fm = fm ; fr.fn = fn ; fr.fp = fp ; fr.rank = frank ; fr.ldn = fn ;
+                fr.Stair = Stair.data ( ) + Rp [f] ;
+                fr.gpuF = dF + FOff [f] ;
+                fr.cpuR = hR + ROff [f] ;
+                fr.is_sparse = 1 ;
+                fr.nc = (int32_t) (Childp [f+1] - Childp [f]) ;
+                fr.Scount = std::max ((Long) 0, Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]]) ;
+                fr.gpuS = dS + SOff [f] ;
+                fr.cn = (int32_t) (fn - fp) ; fr.cm = (int32_t) Cm [f] ;
+                if (parent_mine)
+                {
+                    fr.pn = (int32_t) (Rp [pid+1] - Rp [pid]) ;
+                    fr.gpuRjmap = dRjmap + S->RjmapOffsets [f] ;
+                    fr.gpuRimap = dRimap + S->RimapOffsets [f] ;
+                    fr.gpuC = fr.gpuF + frank * fn + fp ;
+                }
+                else if (pid < nf)
+                {
+                    fr.is_staged = 1 ;
+                }
+                Long child_off = FOff [f] + fm * fn ;
+                for (Long cp = Childp [f] ; cp < Childp [f+1] ; cp++)
+                {
+                    const Long c = Child [cp] ;
+                    if (mine [c]) continue ;
+                    const Long ccn = (Rp [c+1] - Rp [c]) - (Super [c+1] - Super [c]) ;
+                    const Long ccm = Cm [c] ;
+                    gpuqr_front &ch = fronts [next_child] ;
+                    memset (&ch, 0, sizeof (ch)) ;
+                    ch.fids = next_child ; ch.pids = rel [f] ; ch.fidg = c ; ch.pidg = f ;
+                    ch.fm = ccm ; ch.fn = ccn ; ch.ldn = ccn ;
+                    ch.is_sparse = 1 ; ch.push_only = 1 ;
+                    ch.pn = (int32_t) fn ; ch.cm = (int32_t) ccm ; ch.cn = (int32_t) ccn ;
+                    ch.gpuRimap = dRimap + S->RimapOffsets [c] ;
+                    ch.gpuRjmap = dRjmap + S->RjmapOffsets [c] ;
+                    ch.gpuF = ch.gpuC = dF + child_off ;
+                    if (ccm * ccn > 0)
+                    {
+                        if (!limbo_in || !limbo_in [c]) { code = 3 ; goto done ; }
+                        HIPCHK (hipMemcpy (ch.gpuF, limbo_in [c], (size_t) (ccm * ccn) * sizeof (double), hipMemcpyHostToDevice)) ;
+                    }
+                    child_off += ccm * ccn ;
+                    next_child++ ;
+                }
+            }
+
+            gpuqr_stats stats ;
+            int ecode = gpuqr_factor_sparse (S->gpuMemorySize, fronts, next_child, Parent, Childp, Child, &stats) ;
+            if (ecode != GPUQR_SUCCESS) { code = (ecode == GPUQR_OUTOFMEMORY) ? 1 : 2 ; goto done ; }
+            num->gpuKernelTime = stats.kernelTime ;
+            num->gpuFlops = stats.flopsActual ;
+            num->gpuNumKernelLaunches = stats.numLaunches ;
+            num->numStagesRun = 1 ;
+
+            Long rhead = 0, chead = 0 ;
+            for (Long f = 0 ; f < nf ; f++)
+            {
+                if (!mine [f]) continue ;
+                const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
+                const Long frank = std::min (fm, fp) ;
+                const double *cpuF = fronts [rel [f]].cpuR ;
+                num->Rblock [f] = rhead ;
+                double *out = num->Rstack + rhead ;
+                for (Long j = 0 ; j < fn ; j++)
+                {
+                    const Long top = std::min (j + 1, frank) ;
+                    for (Long i = 0 ; i < top ; i++) *out++ = cpuF [fn*i + j] ;
+                }
+                rhead = out - num->Rstack ;
+                if (fronts [rel [f]].is_staged)
+                {
+                    const Long cn = fn - fp, cm = Cm [f] ;
+                    const double *C = cpuF + frank * fn + fp ;
+                    double *L = num->Cstack + chead ;
+                    num->Cblock [f] = chead ;
+                    for (Long i = 0 ; i < cm ; i++) for (Long j = i ; j < cn ; j++) L [i*cn + j] = C [i*fn + j] ;
+                    chead += cm * cn ;
+                }
+            }
+        }
+        for (Long f = 0 ; f < nf ; f++)
+        {
+            const Long fm = Fm [f], fp = Super [f+1] - Super [f] ;
+            for (Long k = fm ; k < fp ; k++) num->Rdead [Super [f] + k] = 1 ;
+            if (mine [f]) { num->sumfrank += std::min (fm, fp) ; num->maxfrank = std::max (num->maxfrank, std::min (fm, fp)) ; }
+        }
+    }
+    catch (std::bad_alloc &)
+    {
+        code = 1 ;
+    }
+
+done:
+    free (fronts) ;
+    if (dF) (void) hipFree (dF) ;
+    if (dS) (void) hipFree (dS) ;
+    if (dRimap) (void) hipFree (dRimap) ;
+    if (dRjmap) (void) hipFree (dRjmap) ;
+    if (hR) (void) hipHostFree (hR) ;
+    if (hS) (void) hipHostFree (hS) ;
+    if (code != 0) { spqr_amd_numeric_free (num) ; return code ; }
+    *num_out = num ;
     return 0 ;
 }

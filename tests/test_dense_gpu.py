@@ -104,3 +104,13 @@ def test_zero_and_rank_deficient_columns():
     (R,), _ = run_dense([A])
     assert gram_resid(R, A) <= 1e-12
     assert abs(R[20, 20]) <= 1e-12 * np.abs(R).max()
+
+
+def test_cpp_demo_program():
+    """The reference's dense demo restated in C++ against the shim header (built by build())."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "demo_dense")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all dense demo experiments pass" in out.stdout

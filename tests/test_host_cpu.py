@@ -197,3 +197,13 @@ def test_error_codes_without_compute():
     assert L.gpuqr_factor_dense(0, None, 0, None) == _lib.GPUQR_SUCCESS
     assert L.gpuqr_factor_sparse(0, None, 3, None, None, None, None) == _lib.GPUQR_GPUERROR
     assert L.gpuqr_front_flops(4096, 2048, None) > 2 * 2048 ** 2 * (4096 - 2048 / 3)
+
+
+def test_cpp_shim_compiles_and_links():
+    """A C++ program written against the reference's header names (Front, SparseMeta, the two
+    GPUQREngine overloads) builds against include/GPUQREngine.hpp and links to the library."""
+    import subprocess
+    d = os.path.join(ROOT, "tests", "cpp")
+    subprocess.check_call(["make", "-s", "-C", d])
+    out = subprocess.check_output([os.path.join(d, "demo_dense"), "linkcheck"]).decode()
+    assert "compiled and linked" in out

@@ -90,3 +90,25 @@ def test_rank_deficient_hits_the_wall():
     res = spqr.factorize(sym, A)
     assert res.rank < 4 and res.rank == int(sum(min(sym.Fm[f], sym.Super[f + 1] - sym.Super[f]) for f in range(sym.nf)))
     assert res.Rdead.sum() == 4 - res.rank
+
+
+def test_subtree_parallel_two_ranks_on_one_gpu(tmp_path):
+    """Two processes (gloo exchange) sharing the test box's one GPU: each factorizes its subtrees
+    with spqrgpu_amd_factorize_subset, rank 0 receives the contribution blocks and finishes the top."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "R.npz")
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "mgpu_worker.py"), "gloo-gpu", out, "20x20"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=110)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    z = np.load(out)
+    R = sp.csc_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"])).toarray()
+    A = problems.stacked_ls((20, 20))
+    Rl = np.linalg.qr(A[:, z["Qfill"]].toarray(), mode="r")
+    assert int(z["n_cut"]) >= 2
+    assert r_rel_diff(rownorm_sign(R), rownorm_sign(Rl)) <= 1e-12
