@@ -184,7 +184,57 @@ extern "C" void spqrgpu_amd_build_assembly_maps
 // numeric driver
 // -----------------------------------------------------------------------------
 
+#include <thread>
+#include <atomic>
+
+// Run body(k) for k in [0,n) on a few host threads (dynamic, one index at a time).
+template <class Body> static void parallel_for (Long n, Body body)
+{
+    unsigned hw = std::thread::hardware_concurrency ( ) ;
+    const char *env = getenv ("OMP_NUM_THREADS") ;
+    long want = env ? atol (env) : 16 ;
+    if (want < 1) want = 1 ;
+    unsigned nt = (unsigned) std::min<long> (want, hw ? hw : 1) ;
+    if (nt > 16) nt = 16 ;
+    if (n < 64 || nt <= 1) { for (Long k = 0 ; k < n ; k++) body (k) ; return ; }
+    std::atomic<Long> next (0) ;
+    std::vector<std::thread> pool ;
+    auto work = [&] ( ) { for (Long k = next.fetch_add (16) ; k < n ; k = next.fetch_add (16))
+        for (Long q = k ; q < std::min (k + 16, n) ; q++) body (q) ; } ;
+    for (unsigned t = 1 ; t < nt ; t++) pool.emplace_back (work) ;
+    work ( ) ;
+    for (size_t t = 0 ; t < pool.size ( ) ; t++) pool [t].join ( ) ;
+}
+
+// The first frank rows of a reduced front (row-major, unpacked) -> SPQR's column-packed upper
+// trapezoid (spqrgpu_kernel.cpp:417-439), walking the source row by row so that the reads
+// from the pinned pull buffer are contiguous.  Column j holds min(j+1, frank) entries.
+static void pack_r_block (const double *cpuF, Long fn, Long frank, double *out)
+{
+    const Long tri = frank * (frank + 1) / 2 ;
+    for (Long i = 0 ; i < frank ; i++)
+    {
+        const double *row = cpuF + fn * i ;
+        for (Long j = i ; j < frank ; j++) out [j * (j + 1) / 2 + i] = row [j] ;
+        double *rect = out + tri + i ;
+        for (Long j = frank ; j < fn ; j++) rect [(j - frank) * frank] = row [j] ;
+    }
+}
+
+static inline Long r_block_size (Long fn, Long frank)
+{
+    return frank * (frank + 1) / 2 + frank * (fn - frank) ;
+}
+
 #define HIPCHK(call) do { if ((call) != hipSuccess) { code = 2 ; goto done ; } } while (0)
+
+#include <chrono>
+static double now_ms (void)
+{
+    return std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now ( ).time_since_epoch ( )).count ( ) ;
+}
+// GPUQR_VERBOSE=1 prints where the host time of the numeric driver goes
+#define TICK(label) do { if (verbose) { double t_ = now_ms ( ) ; fprintf (stderr, "  [spqrgpu] %-28s %9.2f ms\n", label, t_ - tlast) ; tlast = t_ ; } } while (0)
 
 extern "C" void spqr_amd_numeric_free (spqr_amd_numeric *num)
 {
@@ -208,6 +258,8 @@ extern "C" int spqrgpu_amd_factorize
     if (!S || !Ap || !Ax || !num_out) return 3 ;
     *num_out = NULL ;
     int code = 0 ;
+    const bool verbose = getenv ("GPUQR_VERBOSE") != NULL ;
+    double tlast = now_ms ( ) ;
     const Long nf = S->nf, n = S->n, m = S->m ;
     const Long *Super = S->Super.data ( ), *Rp = S->Rp.data ( ), *Post = S->Post.data ( ) ;
     const Long *Parent = S->Parent.data ( ), *Childp = S->Childp.data ( ), *Child = S->Child.data ( ) ;
@@ -242,6 +294,7 @@ extern "C" int spqrgpu_amd_factorize
             }
         }
 
+        TICK ("alloc + Sx") ;
         // ---- maps and packed S for the whole problem ---------------------------------------
         const Long RimapSize = std::max ((Long) 1, S->RimapSize), RjmapSize = std::max ((Long) 1, S->RjmapSize) ;
         std::vector<Long> Stair ((size_t) std::max ((Long) 1, Rp [nf])), Fmap ((size_t) std::max ((Long) 1, n)) ;
@@ -255,6 +308,7 @@ extern "C" int spqrgpu_amd_factorize
         HIPCHK (hipMemcpy (dRimap, Rimap.data ( ), RimapSize * sizeof (int32_t), hipMemcpyHostToDevice)) ;
         HIPCHK (hipMemcpy (dRjmap, Rjmap.data ( ), RjmapSize * sizeof (int32_t), hipMemcpyHostToDevice)) ;
 
+        TICK ("assembly maps + upload") ;
         // ---- workspaces sized for the largest stage -----------------------------------------
         size_t maxF = 1, maxR = 1, maxS = 1 ; Long maxfronts = 1 ;
         for (Long st = 0 ; st < S->numStages ; st++)
@@ -276,6 +330,7 @@ extern "C" int spqrgpu_amd_factorize
         for (Long k = 0 ; k < nf ; k++) InvPost [Post [k]] = k ;
         InvPost [nf] = nf ;
 
+        TICK ("workspace allocation") ;
         Long SOffset = 0 ;
         Long rhead = 0 ;            // next free slot of Rstack
         for (Long stage = 0 ; stage < S->numStages ; stage++)
@@ -353,9 +408,11 @@ extern "C" int spqrgpu_amd_factorize
                 }
             }
 
+            TICK ("stage setup (memset, S, fronts)") ;
             // ---- the device work ---------------------------------------------------------------
             gpuqr_stats stats ;
             int ecode = gpuqr_factor_sparse (S->gpuMemorySize, fronts, next_child, Parent, Childp, Child, &stats) ;
+            TICK ("engine") ;
             if (ecode != GPUQR_SUCCESS) { code = (ecode == GPUQR_OUTOFMEMORY) ? 1 : 2 ; goto done ; }
             num->gpuKernelTime += stats.kernelTime ;
             num->gpuFlops += stats.flopsActual ;
@@ -363,39 +420,53 @@ extern "C" int spqrgpu_amd_factorize
             num->numStagesRun++ ;
 
             // ---- R onto the stack (column-packed), staged C blocks into limbo ---------------------
-            for (Long p = sStart ; p < sEnd ; p++)
             {
-                const Long f = Post [p] ;
-                const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
-                const Long frank = std::min (fm, fp) ;
-                const double *cpuF = fronts [p - sStart].cpuR ;
-                num->Rblock [f] = rhead ;
-                double *out = num->Rstack + rhead ;
-                for (Long j = 0 ; j < fn ; j++)
+                std::vector<Long> roff ((size_t) numFronts + 1) ;
+                roff [0] = rhead ;
+                for (Long p = sStart ; p < sEnd ; p++)
                 {
-                    const Long top = std::min (j + 1, frank) ;
-                    for (Long i = 0 ; i < top ; i++) *out++ = cpuF [fn*i + j] ;
+                    const Long f = Post [p] ;
+                    const Long fn = Rp [f+1] - Rp [f] ;
+                    const Long frank = std::min (Fm [f], Super [f+1] - Super [f]) ;
+                    num->Rblock [f] = roff [p - sStart] ;
+                    roff [p - sStart + 1] = roff [p - sStart] + r_block_size (fn, frank) ;
                 }
-                rhead = out - num->Rstack ;
-                if (fronts [p - sStart].is_staged)
+                rhead = roff [numFronts] ;
+                std::atomic<int> oom (0) ;
+                parallel_for (numFronts, [&] (Long k)
                 {
-                    const Long cn = fn - fp, cm = std::min (fm - frank, cn) ;
-                    const double *C = cpuF + frank * fn + fp ;
-                    double *L = (double *) calloc ((size_t) std::max ((Long) 1, cm * cn), sizeof (double)) ;
-                    if (!L) { code = 1 ; goto done ; }
-                    for (Long i = 0 ; i < cm ; i++) for (Long j = i ; j < cn ; j++) L [i*cn + j] = C [i*fn + j] ;
-                    limbo [f] = L ;
-                }
-                // assembly traffic: 24 B per S entry, 16 B per C entry + 4 B per map int
-                num->assembleBytes += 24.0 * (double) fronts [p - sStart].Scount ;
-                if (Cm [f] > 0 && fn - fp > 0 && Parent [f] < nf)
+                    const Long f = Post [sStart + k] ;
+                    const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
+                    const Long frank = std::min (fm, fp) ;
+                    const double *cpuF = fronts [k].cpuR ;
+                    pack_r_block (cpuF, fn, frank, num->Rstack + roff [k]) ;
+                    if (fronts [k].is_staged)
+                    {
+                        const Long cn = fn - fp, cm = std::min (fm - frank, cn) ;
+                        const double *C = cpuF + frank * fn + fp ;
+                        double *L = (double *) calloc ((size_t) std::max ((Long) 1, cm * cn), sizeof (double)) ;
+                        if (!L) { oom = 1 ; return ; }
+                        for (Long i = 0 ; i < cm ; i++) for (Long j = i ; j < cn ; j++) L [i*cn + j] = C [i*fn + j] ;
+                        limbo [f] = L ;
+                    }
+                }) ;
+                if (oom) { code = 1 ; goto done ; }
+                for (Long p = sStart ; p < sEnd ; p++)
                 {
-                    const double cmm = (double) Cm [f], cnn = (double) (fn - fp) ;
-                    num->assembleBytes += 16.0 * (cmm * (cmm + 1) / 2 + cmm * (cnn - cmm)) + 4.0 * (cmm + cnn) ;
+                    const Long f = Post [p] ;
+                    const Long fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
+                    // assembly traffic: 24 B per S entry, 16 B per C entry + 4 B per map int
+                    num->assembleBytes += 24.0 * (double) fronts [p - sStart].Scount ;
+                    if (Cm [f] > 0 && fn - fp > 0 && Parent [f] < nf)
+                    {
+                        const double cmm = (double) Cm [f], cnn = (double) (fn - fp) ;
+                        num->assembleBytes += 16.0 * (cmm * (cmm + 1) / 2 + cmm * (cnn - cmm)) + 4.0 * (cmm + cnn) ;
+                    }
                 }
             }
         }
 
+        TICK ("R pack") ;
         // ---- ranks and dead columns (no rank detection on the device) ----------------------------
         for (Long f = 0 ; f < nf ; f++)
         {
@@ -657,30 +728,34 @@ extern "C" int spqrgpu_amd_factorize_subset
             num->gpuNumKernelLaunches = stats.numLaunches ;
             num->numStagesRun = 1 ;
 
-            Long rhead = 0, chead = 0 ;
-            for (Long f = 0 ; f < nf ; f++)
             {
-                if (!mine [f]) continue ;
-                const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
-                const Long frank = std::min (fm, fp) ;
-                const double *cpuF = fronts [rel [f]].cpuR ;
-                num->Rblock [f] = rhead ;
-                double *out = num->Rstack + rhead ;
-                for (Long j = 0 ; j < fn ; j++)
+                std::vector<Long> mylist, roff, coff ;
+                Long rhead = 0, chead = 0 ;
+                for (Long f = 0 ; f < nf ; f++)
                 {
-                    const Long top = std::min (j + 1, frank) ;
-                    for (Long i = 0 ; i < top ; i++) *out++ = cpuF [fn*i + j] ;
+                    if (!mine [f]) continue ;
+                    const Long fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
+                    const Long frank = std::min (Fm [f], fp) ;
+                    mylist.push_back (f) ; roff.push_back (rhead) ; coff.push_back (chead) ;
+                    num->Rblock [f] = rhead ;
+                    rhead += r_block_size (fn, frank) ;
+                    if (fronts [rel [f]].is_staged) { num->Cblock [f] = chead ; chead += Cm [f] * (fn - fp) ; }
                 }
-                rhead = out - num->Rstack ;
-                if (fronts [rel [f]].is_staged)
+                parallel_for ((Long) mylist.size ( ), [&] (Long k)
                 {
-                    const Long cn = fn - fp, cm = Cm [f] ;
-                    const double *C = cpuF + frank * fn + fp ;
-                    double *L = num->Cstack + chead ;
-                    num->Cblock [f] = chead ;
-                    for (Long i = 0 ; i < cm ; i++) for (Long j = i ; j < cn ; j++) L [i*cn + j] = C [i*fn + j] ;
-                    chead += cm * cn ;
-                }
+                    const Long f = mylist [k] ;
+                    const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
+                    const Long frank = std::min (fm, fp) ;
+                    const double *cpuF = fronts [rel [f]].cpuR ;
+                    pack_r_block (cpuF, fn, frank, num->Rstack + roff [k]) ;
+                    if (fronts [rel [f]].is_staged)
+                    {
+                        const Long cn = fn - fp, cm = Cm [f] ;
+                        const double *C = cpuF + frank * fn + fp ;
+                        double *L = num->Cstack + coff [k] ;
+                        for (Long i = 0 ; i < cm ; i++) for (Long j = i ; j < cn ; j++) L [i*cn + j] = C [i*fn + j] ;
+                    }
+                }) ;
             }
         }
         for (Long f = 0 ; f < nf ; f++)

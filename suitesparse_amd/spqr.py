@@ -100,8 +100,9 @@ class NumericResult:
     pass
 
 
-def factorize(sym, A):
-    """spqrgpu_amd_factorize + spqr_amd_rconvert: returns R (scipy CSC, sumfrank-by-n) and stats."""
+def factorize(sym, A, want_R=True):
+    """spqrgpu_amd_factorize (+ spqr_amd_rconvert when want_R): returns R (scipy CSC,
+    sumfrank-by-n) and stats."""
     L = _bind()
     A = sp.csc_matrix(A)
     A.sort_indices()
@@ -112,15 +113,17 @@ def factorize(sym, A):
         raise RuntimeError("spqrgpu_amd_factorize failed with code %d" % code)
     num = out.contents
     n = sym.n
-    Rp = np.zeros(n + 1, dtype=np.int64)
-    L.spqr_amd_rconvert(sym._h, out, _p(Rp), None, None)
-    Ri = np.zeros(max(int(Rp[n]), 1), dtype=np.int64)
-    Rx = np.zeros(max(int(Rp[n]), 1), dtype=np.float64)
-    L.spqr_amd_rconvert(sym._h, out, _p(Rp), _p(Ri), _p(Rx))
     res = NumericResult()
     res.rank = int(num.sumfrank)
     res.maxfrank = int(num.maxfrank)
-    res.R = sp.csc_matrix((Rx[:Rp[n]], Ri[:Rp[n]], Rp), shape=(max(res.rank, 0), n))
+    res.R = None
+    if want_R:
+        Rp = np.zeros(n + 1, dtype=np.int64)
+        L.spqr_amd_rconvert(sym._h, out, _p(Rp), None, None)
+        Ri = np.zeros(max(int(Rp[n]), 1), dtype=np.int64)
+        Rx = np.zeros(max(int(Rp[n]), 1), dtype=np.float64)
+        L.spqr_amd_rconvert(sym._h, out, _p(Rp), _p(Ri), _p(Rx))
+        res.R = sp.csc_matrix((Rx[:Rp[n]], Ri[:Rp[n]], Rp), shape=(max(res.rank, 0), n))
     res.Rdead = np.frombuffer(C.string_at(num.Rdead, n), dtype=np.int8).copy() if n > 0 else np.zeros(0, np.int8)
     res.gpuKernelTime = float(num.gpuKernelTime)
     res.gpuFlops = int(num.gpuFlops)
