@@ -36,14 +36,6 @@ class Stats(C.Structure):
     _fields_ = [("kernelTime", C.c_float), ("numLaunches", C.c_int64), ("flopsActual", C.c_int64)]
 
 
-EXPORTS = [
-    "gpuqr_factor_dense", "gpuqr_factor_sparse", "gpuqr_find_staircase", "gpuqr_max_queue_size",
-    "gpuqr_front_flops", "gpuqr_set_allocator", "gpuqr_device_count", "gpuqr_version",
-    "spqrgpu_amd_compute_front_staging", "spqrgpu_amd_build_assembly_maps",
-    "spqrgpu_amd_numfronts_in_stage", "spqrgpu_amd_factorize",
-    "spqr_amd_analyze", "spqr_amd_symbolic_free", "spqr_amd_symbolic_get",
-]
-
 _lib = None
 
 
@@ -70,5 +62,7 @@ def lib():
     L.gpuqr_front_flops.restype = C.c_int64
     L.gpuqr_device_count.restype = C.c_int
     L.gpuqr_version.restype = C.c_int
+    L.gpuqr_set_mode.argtypes = [C.c_int]
+    L.gpuqr_set_mode.restype = None
     _lib = L
     return L

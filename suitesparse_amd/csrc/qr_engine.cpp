@@ -36,6 +36,8 @@
 extern "C" int        qr_task_kernel_id (int type, int tier) ;
 extern "C" hipError_t qr_launch_tasks (int kid, const QrTask *d_tasks, const QrRef *d_refs, int nrefs, hipStream_t stream) ;
 extern "C" hipError_t qr_kernels_init (void) ;
+extern "C" hipError_t qr_launch_persistent (const QrTask *d_tasks, const QrQueueRef *d_refs, int nrefs,
+    int *d_counters, int nworkgroups, hipStream_t stream) ;
 
 #define QR_NKERNELS 9
 
@@ -124,6 +126,8 @@ struct SchedTask
     int32_t round ;
     int64_t vt ;        // VT tile index or -1
     int32_t nblk ;      // workgroups this task is run by (apply: column blocks; else 1)
+    int32_t wait_ctr ;  // work queue: counter (= front) whose earlier rounds this task waits for
+    int32_t signal_ctr ;// work queue: counter this task reports to (the parent's, for pack assembly)
     double  flops ;     // algorithmic flops of this task
     double  bytes ;     // algorithmic (minimum) bytes it moves to and from memory
 } ;
@@ -132,8 +136,18 @@ struct SchedTask
 // optional per-kernel profile (HIP events around every launch)
 // -----------------------------------------------------------------------------
 
-static int g_stagger = 1 ;     // start rounds of childless fronts are spread over this many rounds
-extern "C" void gpuqr_set_stagger (int rounds) { g_stagger = rounds ; }
+// 0: one launch per (round, kernel) on two streams; 1: one persistent work-queue kernel per call
+static int g_mode = -1 ;
+extern "C" void gpuqr_set_mode (int mode) { g_mode = mode ; }
+static int engine_mode (void)
+{
+    if (g_mode < 0) { const char *e = getenv ("GPUQR_MODE") ; g_mode = e ? atoi (e) : 0 ; }
+    return g_mode ;
+}
+
+// Start rounds of childless fronts can be spread over this many rounds so that panel and apply
+// kernels of different fronts overlap; measured slower than starting them together, so off.
+static const int g_stagger = 1 ;
 
 struct KernelProfile { double ms, flops, bytes ; int64_t launches, tasks ; } ;
 static int g_profile_on = 0 ;
@@ -364,8 +378,9 @@ struct DeviceCache
     hipStream_t sCompute = NULL, sApply = NULL, sCopy = NULL ;
     hipEvent_t evStart = NULL, evStop = NULL ;
     std::vector<hipEvent_t> evPool ;        // untimed events, reused by every call
-    void *d_tasks = NULL, *d_refs = NULL, *d_vt = NULL, *h_stage = NULL ;
-    size_t cap_tasks = 0, cap_refs = 0, cap_vt = 0, cap_stage = 0 ;
+    void *d_tasks = NULL, *d_refs = NULL, *d_vt = NULL, *h_stage = NULL, *d_counters = NULL ;
+    size_t cap_tasks = 0, cap_refs = 0, cap_vt = 0, cap_stage = 0, cap_counters = 0 ;
+    int num_cus = 0 ;
 
     hipError_t ensure (void **p, size_t *cap, size_t need, bool pinned_host)
     {
@@ -400,6 +415,7 @@ struct DeviceCache
         if (d_tasks) (void) hipFree (d_tasks) ;
         if (d_refs) (void) hipFree (d_refs) ;
         if (d_vt) (void) hipFree (d_vt) ;
+        if (d_counters) (void) hipFree (d_counters) ;
         if (h_stage) (void) hipHostFree (h_stage) ;
         *this = DeviceCache ( ) ;
     }
@@ -425,6 +441,7 @@ static DeviceCache *device_cache (void)
         if (hipEventCreate (&dc->evStart) != hipSuccess) { dc->release ( ) ; return NULL ; }
         if (hipEventCreate (&dc->evStop) != hipSuccess) { dc->release ( ) ; return NULL ; }
         if (qr_kernels_init ( ) != hipSuccess) { dc->release ( ) ; return NULL ; }
+        if (hipDeviceGetAttribute (&dc->num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || dc->num_cus <= 0) dc->num_cus = 256 ;
         dc->ready = true ;
     }
     return dc ;
@@ -505,6 +522,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
             const int64_t f = order [k] ;
             gpuqr_front &fr = fronts [f] ;
             int32_t done = 0 ;
+            const size_t first_task = plan.tasks.size ( ) ;
             if (!(fr.is_sparse && fr.push_only))
             {
                 // S assembly, round 0
@@ -532,6 +550,10 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                 if (done < start - 1) done = start - 1 ;
             }
             done_round [f] = done ;
+            for (size_t i = first_task ; i < plan.tasks.size ( ) ; i++)
+            {
+                plan.tasks [i].wait_ctr = (int32_t) f ; plan.tasks [i].signal_ctr = (int32_t) f ;
+            }
             // pack assembly into the parent
             if (fr.is_sparse && fr.pids >= 0 && fr.cm > 0 && fr.cn > 0)
             {
@@ -550,6 +572,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                         pk.cistart = ci ; pk.ciend = std::min (ci + QR_PACK_TILE, fr.cm) ;
                         pk.cjstart = cj ; pk.cjend = std::min (cj + QR_PACK_TILE, fr.cn) ;
                         st.round = round ; st.vt = -1 ; st.nblk = 1 ;
+                        st.wait_ctr = (int32_t) f ; st.signal_ctr = (int32_t) fr.pids ;
                         {
                             // entries of the tile on or above the diagonal: 8 read + 8 written, plus the map ints
                             double cnt = 0 ;
@@ -596,6 +619,133 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
         if (!dc) { code = GPUQR_GPUERROR ; goto cleanup ; }
         sCompute = dc->sCompute ; sApply = dc->sApply ; sCopy = dc->sCopy ; evStart = dc->evStart ; evStop = dc->evStop ;
 
+        if (ntasks > 0 && engine_mode ( ) == 1 && !g_profile_on)
+        {
+            // ---- one persistent kernel: the same tasks in the same order, with arrival counters ----
+            // Counter c counts the finished workgroups that report to front c: its own tasks and the
+            // pack-assembly tasks of its children.  A task of round r waits until everything reporting
+            // to its front from rounds < r has arrived, i.e. rounds stay barriers inside a front, while
+            // different fronts run free of each other.
+            const size_t task_bytes = (size_t) ntasks * sizeof (QrTask) ;
+            const size_t ref_bytes = (size_t) nrefs * sizeof (QrQueueRef) ;
+#ifdef PQ_STATS
+            const size_t ctr_bytes = ((size_t) (QR_QUEUE_FIRST + std::max<int64_t> (nf, 1100)) * sizeof (int) + 15) & ~(size_t) 15 ;
+#else
+            const size_t ctr_bytes = ((size_t) (QR_QUEUE_FIRST + nf) * sizeof (int) + 15) & ~(size_t) 15 ;
+#endif
+            HIP_TRY (dc->ensure (&dc->d_vt, &dc->cap_vt, (size_t) plan.n_vt * QR_VT_DOUBLES * sizeof (double), false)) ;
+            HIP_TRY (dc->ensure (&dc->d_tasks, &dc->cap_tasks, task_bytes, false)) ;
+            HIP_TRY (dc->ensure (&dc->d_refs, &dc->cap_refs, ref_bytes, false)) ;
+            HIP_TRY (dc->ensure (&dc->d_counters, &dc->cap_counters, ctr_bytes, false)) ;
+            HIP_TRY (dc->ensure (&dc->h_stage, &dc->cap_stage, task_bytes + ref_bytes, true)) ;
+            d_vt = (double *) dc->d_vt ; d_tasks = (QrTask *) dc->d_tasks ;
+            QrQueueRef *d_qrefs = (QrQueueRef *) dc->d_refs ;
+            QrTask *h_tasks = (QrTask *) dc->h_stage ;
+            QrQueueRef *h_qrefs = (QrQueueRef *) ((char *) dc->h_stage + task_bytes) ;
+
+            // arrivals per (counter, round), as prefix sums over the rounds of each counter
+            hvec<int64_t> cptr ((size_t) nf + 1, 0) ;
+            for (int64_t i = 0 ; i < ntasks ; i++) cptr [plan.tasks [i].signal_ctr + 1]++ ;
+            for (int64_t c = 0 ; c < nf ; c++) cptr [c+1] += cptr [c] ;
+            hvec<int64_t> cidx ((size_t) ntasks) ;
+            {
+                hvec<int64_t> w (cptr) ;
+                for (int64_t i = 0 ; i < ntasks ; i++) cidx [w [plan.tasks [i].signal_ctr]++] = i ;
+            }
+            hvec<int32_t> cround ((size_t) ntasks), ccum ((size_t) ntasks) ;
+            for (int64_t c = 0 ; c < nf ; c++)
+            {
+                std::sort (cidx.begin ( ) + cptr [c], cidx.begin ( ) + cptr [c+1], [&] (int64_t a, int64_t b)
+                    { return plan.tasks [a].round < plan.tasks [b].round ; }) ;
+                int64_t cum = 0 ;
+                for (int64_t k = cptr [c] ; k < cptr [c+1] ; k++)
+                {
+                    cround [k] = plan.tasks [cidx [k]].round ;
+                    ccum [k] = (int32_t) cum ;               // arrivals from entries before this one
+                    cum += plan.tasks [cidx [k]].nblk ;
+                }
+            }
+            {
+                hvec<int64_t> pos (rptr) ;
+                for (int64_t i = 0 ; i < ntasks ; i++)
+                {
+                    SchedTask &st = plan.tasks [i] ;
+                    if (st.t.type == QR_TASK_FACTORIZE || st.t.type == QR_TASK_APPLY)
+                    {
+                        QrPanelTask &pt = st.t.u.panel ;
+                        pt.VT = (st.vt >= 0) ? d_vt + (size_t) st.vt * QR_VT_DOUBLES : NULL ;
+                        bool ok = pt.K >= 1 && pt.K <= QR_MAX_K && pt.w >= 1 && pt.w <= QR_PANEL_W
+                            && pt.nseg >= 1 && pt.nseg <= QR_MAX_SEG && pt.col0 >= 0 && pt.col0 + pt.w <= pt.ld
+                            && (st.t.type == QR_TASK_FACTORIZE || (pt.VT != NULL && pt.c_begin >= 0
+                                && pt.c_begin < pt.c_end && pt.c_end <= pt.ld && pt.cb_cols >= 16
+                                && (int64_t) (st.nblk - 1) * pt.cb_cols < pt.c_end - pt.c_begin)) ;
+                        int acc = 0 ;
+                        for (int s = 0 ; s < pt.nseg && ok ; s++) { ok = pt.seg_row [s] >= 0 && pt.seg_n [s] >= 1 ; acc += pt.seg_n [s] ; }
+                        if (!ok || acc != pt.K) { code = GPUQR_GPUERROR ; goto cleanup ; }
+                    }
+                    h_tasks [i] = st.t ;
+                    // arrivals at the waited-for counter from rounds before this task's
+                    const int64_t c = st.wait_ctr ;
+                    const int32_t *lo = cround.data ( ) + cptr [c], *hi = cround.data ( ) + cptr [c+1] ;
+                    const int32_t *it = std::lower_bound (lo, hi, st.round) ;
+                    int32_t need = 0 ;
+                    if (it != hi) need = ccum [cptr [c] + (it - lo)] ;
+                    else if (hi != lo)
+                    {
+                        const int64_t last = cptr [c+1] - 1 ;
+                        need = ccum [last] + plan.tasks [cidx [last]].nblk ;
+                    }
+                    int64_t &q = pos [(int64_t) st.round * QR_NKERNELS + qr_task_kernel_id (st.t.type, st.t.tier)] ;
+                    for (int32_t b = 0 ; b < st.nblk ; b++)
+                    {
+                        QrQueueRef &qr = h_qrefs [q++] ;
+                        qr.task = (int32_t) i ; qr.blk = b ; qr.wait_ctr = st.wait_ctr ; qr.need = need ;
+                        qr.signal_ctr = st.signal_ctr ;
+                    }
+                }
+            }
+            HIP_TRY (hipMemcpyAsync (d_tasks, h_tasks, task_bytes, hipMemcpyHostToDevice, sCompute)) ;
+            HIP_TRY (hipMemcpyAsync (d_qrefs, h_qrefs, ref_bytes, hipMemcpyHostToDevice, sCompute)) ;
+            HIP_TRY (hipMemsetAsync (dc->d_counters, 0, ctr_bytes, sCompute)) ;
+            HIP_TRY (hipEventRecord (evStart, sCompute)) ;
+            {
+                int64_t nwg = std::min<int64_t> (nrefs, (int64_t) 2 * dc->num_cus) ;
+                HIP_TRY (qr_launch_persistent (d_tasks, d_qrefs, (int) nrefs, (int *) dc->d_counters, (int) nwg, sCompute)) ;
+                launches = 1 ;
+            }
+            HIP_TRY (hipEventRecord (evStop, sCompute)) ;
+            int qstate [2] = {0, 0} ;
+            HIP_TRY (hipMemcpyAsync (qstate, dc->d_counters, sizeof (qstate), hipMemcpyDeviceToHost, sCompute)) ;
+            for (int64_t f = 0 ; f < nf ; f++)
+            {
+                gpuqr_front &fr = fronts [f] ;
+                if (fr.cpuR == NULL || (fr.is_sparse && fr.push_only)) continue ;
+                int64_t nvals = fr.rank * fr.fn ;
+                if (fr.is_sparse && fr.is_staged) nvals += (int64_t) fr.cm * fr.fn ;
+                if (nvals > fr.fm * fr.fn) nvals = fr.fm * fr.fn ;
+                if (nvals > 0)
+                    HIP_TRY (hipMemcpyAsync (fr.cpuR, fr.gpuF, (size_t) nvals * sizeof (double), hipMemcpyDeviceToHost, sCompute)) ;
+            }
+            HIP_TRY (hipStreamSynchronize (sCompute)) ;
+            HIP_TRY (hipEventElapsedTime (&ms, evStart, evStop)) ;
+#ifdef PQ_STATS
+            if (nf <= 1000)
+            {
+                unsigned long long st [7] ;
+                HIP_TRY (hipMemcpy (st, (int *) dc->d_counters + 1024, sizeof (st), hipMemcpyDeviceToHost)) ;
+                double tot = (double) st [6] ;
+                fprintf (stderr, "pq stats: kernel %.2f ms; per-WG shares: wait %.1f%% factorize %.1f%% apply %.1f%% assemble %.1f%% publish %.1f%%; tasks %llu, clock ticks per WG %.0f\n",
+                    ms, 100*st [0]/tot, 100*st [1]/tot, 100*st [2]/tot, 100*st [3]/tot, 100*st [4]/tot, st [5], tot / 512) ;
+            }
+#endif
+            if (qstate [QR_QUEUE_ERROR] != 0 || qstate [QR_QUEUE_HEAD] < nrefs)
+            {
+                if (getenv ("GPUQR_VERBOSE")) fprintf (stderr, "gpuqr: work queue stopped early (error %d, head %d of %ld)\n",
+                    qstate [QR_QUEUE_ERROR], qstate [QR_QUEUE_HEAD], (long) nrefs) ;
+                code = GPUQR_GPUERROR ; goto cleanup ;
+            }
+        }
+        else
         if (ntasks > 0)
         {
             const size_t task_bytes = (size_t) ntasks * sizeof (QrTask) ;

@@ -23,6 +23,14 @@
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+// Pointers read out of a task descriptor are generic to the compiler, and every access through
+// one becomes a flat_ instruction that also counts against the LDS counter, so LDS waits would
+// stall on outstanding HBM traffic.  All front, VT, map and S pointers are device memory: naming
+// the global address space gives global_load / global_store, tracked by vmcnt alone.
+typedef __attribute__((address_space(1))) double gdouble ;
+typedef __attribute__((address_space(1))) const double gcdouble ;
+typedef __attribute__((address_space(1))) const int gcint ;
+
 #define HOUSE_EPS 1e-90     // same "column is already zero" threshold as factorize_vt.cu:12
 
 // -----------------------------------------------------------------------------
@@ -75,6 +83,36 @@ struct FactorizeLds
     double tau    [32] ;
 } ;
 
+// T of the compact WY form from the by-products of the panel loop: Z(i,k) = -tau_k v_i'v_k for
+// i < k, tau on the diagonal; T(0:k-1,k) = T(0:k-1,0:k-1) Z(0:k-1,k).  Lane j owns row j of T in
+// registers; T(j,i) = 0 for i < j, so the unmasked sum is the triangular product.  Kept out of
+// line so that its 32 row registers do not add to the register budget of the panel loop.
+__device__ __attribute__((noinline)) void build_t (FactorizeLds &L, const int kmax, const int w, gdouble *VT, const int tid)
+{
+    double trow [32] ;
+    #pragma unroll
+    for (int i = 0 ; i < 32 ; i++) trow [i] = 0 ;
+    #pragma unroll
+    for (int k = 0 ; k < 32 ; k++)
+    {
+        if (k < kmax)
+        {
+            double acc0 = 0, acc1 = 0 ;
+            #pragma unroll
+            for (int i = 0 ; i + 1 < k ; i += 2)
+            {
+                acc0 += trow [i]   * L.Z [i][k] ;
+                acc1 += trow [i+1] * L.Z [i+1][k] ;
+            }
+            if (k & 1) acc0 += trow [k-1] * L.Z [k-1][k] ;
+            trow [k] = (tid < k) ? (acc0 + acc1) : ((tid == k) ? L.tau [k] : 0.0) ;
+        }
+    }
+    #pragma unroll
+    for (int i = 0 ; i < 32 ; i++)
+        if (i >= tid && tid < w && i < w) VT [tid*32 + i] = trow [i] ;
+}
+
 // The 8 Householder steps k = 8*IK .. 8*IK+7.  With rows dealt to threads as
 // r = rg + 8*i, the register slot of the pivot row (i = IK) is a compile-time
 // constant inside this function: slots i < IK lie entirely above the pivot row
@@ -89,7 +127,6 @@ __device__ __forceinline__ void house_steps
     if constexpr (IK < RPT)
     {
         const int wave = tid >> 6 ;
-        double v [RPT] ;
         for (int rgk = 0 ; rgk < 8 ; rgk++)
         {
             const int k = 8*IK + rgk ;
@@ -135,7 +172,6 @@ __device__ __forceinline__ void house_steps
                 double vr ;
                 if (i > IK) vr = vb [rg + 8*i] * inv ;
                 else        vr = (rg > rgk) ? vb [rg + 8*i] * inv : ((rg == rgk) ? 1.0 : 0.0) ;
-                v [i] = vr ;
                 d += vr * a [i] ;
             }
             d += __shfl_xor (d, 32) ;
@@ -143,17 +179,25 @@ __device__ __forceinline__ void house_steps
             __syncthreads ( ) ;
 
             const double z = -tau * ((L.dpart [0][c] + L.dpart [1][c]) + (L.dpart [2][c] + L.dpart [3][c])) ;
+            // v is read again from LDS rather than kept in registers (RPT more live values would
+            // push the 256-row variant past the budget of two waves per SIMD)
             if (c > k)
             {
                 #pragma unroll
-                for (int i = IK ; i < RPT ; i++) a [i] += v [i] * z ;
+                for (int i = IK ; i < RPT ; i++)
+                {
+                    double vr ;
+                    if (i > IK) vr = vb [rg + 8*i] * inv ;
+                    else        vr = (rg > rgk) ? vb [rg + 8*i] * inv : ((rg == rgk) ? 1.0 : 0.0) ;
+                    a [i] += vr * z ;
+                }
             }
             else if (c == k)
             {
                 #pragma unroll
                 for (int i = IK ; i < RPT ; i++)
                 {
-                    if (i > IK || rg > rgk) a [i] = v [i] ;
+                    if (i > IK || rg > rgk) a [i] = vb [rg + 8*i] * inv ;
                     else if (rg == rgk)     a [i] = s ;
                 }
             }
@@ -167,7 +211,7 @@ __device__ __forceinline__ void house_steps
 }
 
 template <int RPT>
-__device__ void factorize_panel (const QrPanelTask &t, char *smem)
+__device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *smem)
 {
     FactorizeLds &L = *reinterpret_cast<FactorizeLds *>(smem) ;
     const int tid = threadIdx.x ;
@@ -175,8 +219,8 @@ __device__ void factorize_panel (const QrPanelTask &t, char *smem)
     const int rg = tid >> 5 ;
     const int K = t.K, w = t.w, ld = t.ld ;
     const int kmax = (K < w) ? K : w ;
-    double *F = t.F ;
-    double *VT = t.VT ;
+    gdouble *F = (gdouble *) t.F ;
+    gdouble *VT = (gdouble *) t.VT ;
 
     build_rowmap (t, L.rowmap, 8*RPT) ;
     for (int i = tid ; i < 32*33 ; i += QR_THREADS) (&L.Z[0][0]) [i] = 0 ;
@@ -219,33 +263,7 @@ __device__ void factorize_panel (const QrPanelTask &t, char *smem)
     if (VT != NULL)
     {
         __syncthreads ( ) ;
-        if (tid < 32)
-        {
-            // lane j owns row j of T in registers; T(j,i) = 0 for i < j, so the
-            // unmasked sum below is the triangular product T(0:k-1,0:k-1) z
-            double trow [32] ;
-            #pragma unroll
-            for (int i = 0 ; i < 32 ; i++) trow [i] = 0 ;
-            #pragma unroll
-            for (int k = 0 ; k < 32 ; k++)
-            {
-                if (k < kmax)
-                {
-                    double acc0 = 0, acc1 = 0 ;
-                    #pragma unroll
-                    for (int i = 0 ; i + 1 < k ; i += 2)
-                    {
-                        acc0 += trow [i]   * L.Z [i][k] ;
-                        acc1 += trow [i+1] * L.Z [i+1][k] ;
-                    }
-                    if (k & 1) acc0 += trow [k-1] * L.Z [k-1][k] ;
-                    trow [k] = (tid < k) ? (acc0 + acc1) : ((tid == k) ? L.tau [k] : 0.0) ;
-                }
-            }
-            #pragma unroll
-            for (int i = 0 ; i < 32 ; i++)
-                if (i >= tid && tid < w && i < w) VT [tid*32 + i] = trow [i] ;
-        }
+        if (tid < 32) build_t (L, kmax, w, VT, tid) ;
     }
 }
 
@@ -267,7 +285,7 @@ __device__ void factorize_panel (const QrPanelTask &t, char *smem)
 #define VS_LD 34
 
 template <int MT>
-__device__ void apply_block (const QrPanelTask &t, const int blk, char *smem)
+__device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk, char *smem)
 {
     double (*Vs)[VS_LD] = reinterpret_cast<double (*)[VS_LD]>(smem) ;                       // [MT*16][34]
     double (*Ts)[VS_LD] = reinterpret_cast<double (*)[VS_LD]>(smem + (size_t) MT*16*VS_LD*8) ; // [32][34]
@@ -276,8 +294,8 @@ __device__ void apply_block (const QrPanelTask &t, const int blk, char *smem)
     const int tid = threadIdx.x ;
     const int K = t.K, w = t.w, ld = t.ld ;
     const int kmax = (K < w) ? K : w ;
-    double *F = t.F ;
-    const double *VT = t.VT ;
+    gdouble *F = (gdouble *) t.F ;
+    gcdouble *VT = (gcdouble *) t.VT ;
 
     build_rowmap (t, rowmap, MT*16) ;
     __syncthreads ( ) ;
@@ -337,8 +355,8 @@ __device__ void apply_block (const QrPanelTask &t, const int blk, char *smem)
         const int ncol = col + 64 ;
         const bool nvalid = (slab + 4 < nslab) && (ncol < c_end) ;
 
-        // step 1: W = V' A, two 16-row tiles of W, two accumulators each
-        v4f64 W0a = {0,0,0,0}, W1a = {0,0,0,0}, W0b = {0,0,0,0}, W1b = {0,0,0,0} ;
+        // step 1: W = V' A, two 16-row tiles of W (two independent accumulation chains)
+        v4f64 W0 = {0,0,0,0}, W1 = {0,0,0,0} ;
         #pragma unroll
         for (int mt = 0 ; mt < MT ; mt++)
         {
@@ -347,19 +365,10 @@ __device__ void apply_block (const QrPanelTask &t, const int blk, char *smem)
             {
                 int r = mt*16 + 4*i + lr ;
                 double b = A [mt][i] ;
-                if (i & 1)
-                {
-                    W0b = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [r][lc],      b, W0b, 0, 0, 0) ;
-                    W1b = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [r][16 + lc], b, W1b, 0, 0, 0) ;
-                }
-                else
-                {
-                    W0a = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [r][lc],      b, W0a, 0, 0, 0) ;
-                    W1a = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [r][16 + lc], b, W1a, 0, 0, 0) ;
-                }
+                W0 = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [r][lc],      b, W0, 0, 0, 0) ;
+                W1 = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [r][16 + lc], b, W1, 0, 0, 0) ;
             }
         }
-        v4f64 W0 = W0a + W0b, W1 = W1a + W1b ;
 
         // step 2: X = T' W (T upper triangular: rows 16..31 of T do not reach X0)
         v4f64 X0 = {0,0,0,0}, X1 = {0,0,0,0} ;
@@ -398,7 +407,7 @@ __device__ void apply_block (const QrPanelTask &t, const int blk, char *smem)
                 int r = mt*16 + 4*i + lr_st ;
                 if (r < K)
                 {
-                    double *rowp = F + (size_t) rowmap [r] * ld ;
+                    gdouble *rowp = F + (size_t) rowmap [r] * ld ;
 #ifdef ABL_NOMEM
                     if (acc [i] == 1.2345e-300) rowp [col] = acc [i] ;
                     A [mt][i] = acc [i] + 1.0 ;
@@ -424,12 +433,13 @@ struct SEntryDev { long long findex ; double value ; } ;    // 16 bytes, GPUQREn
 
 __device__ void sassemble (const QrSAssembleTask &t)
 {
-    const SEntryDev *S = reinterpret_cast<const SEntryDev *>(t.S) ;
-    double *F = t.F ;
+    // an entry is two 8-byte words: index, then the bits of the value
+    typedef __attribute__((address_space(1))) const long long gcll ;
+    gcll *S = (gcll *) t.S ;
+    gdouble *F = (gdouble *) t.F ;
     for (int64_t p = t.pstart + threadIdx.x ; p < t.pend ; p += QR_THREADS)
     {
-        SEntryDev e = S [p] ;
-        F [e.findex] = e.value ;
+        F [S [2*p]] = __longlong_as_double (S [2*p + 1]) ;
     }
 }
 
@@ -439,8 +449,9 @@ __device__ void packassemble (const QrPackAssembleTask &t, char *smem)
     int *shRjmap = shRimap + QR_PACK_TILE ;                 // [QR_PACK_TILE]
     const int ctm = t.ciend - t.cistart ;
     const int ctn = t.cjend - t.cjstart ;
-    for (int p = threadIdx.x ; p < ctm ; p += QR_THREADS) shRimap [p] = t.Rimap [t.cistart + p] ;
-    for (int p = threadIdx.x ; p < ctn ; p += QR_THREADS) shRjmap [p] = t.Rjmap [t.cjstart + p] ;
+    gcint *Rimap = (gcint *) t.Rimap, *Rjmap = (gcint *) t.Rjmap ;
+    for (int p = threadIdx.x ; p < ctm ; p += QR_THREADS) shRimap [p] = Rimap [t.cistart + p] ;
+    for (int p = threadIdx.x ; p < ctn ; p += QR_THREADS) shRjmap [p] = Rjmap [t.cjstart + p] ;
     __syncthreads ( ) ;
     // one wave per row of the tile, lanes along the (contiguous) child columns;
     // only the upper trapezoid cj >= ci carries data (packAssemble.cu:47-55)
@@ -448,8 +459,8 @@ __device__ void packassemble (const QrPackAssembleTask &t, char *smem)
     for (int cil = wave ; cil < ctm ; cil += 4)
     {
         const int ci = t.cistart + cil ;
-        const double *Crow = t.C + (size_t) ci * t.cld ;
-        double *Prow = t.P + (size_t) shRimap [cil] * t.pn ;
+        gcdouble *Crow = (gcdouble *) t.C + (size_t) ci * t.cld ;
+        gdouble *Prow = (gdouble *) t.P + (size_t) shRimap [cil] * t.pn ;
         for (int cjl = lane ; cjl < ctn ; cjl += 64)
         {
             int cj = t.cjstart + cjl ;
@@ -463,7 +474,7 @@ __device__ void packassemble (const QrPackAssembleTask &t, char *smem)
 // -----------------------------------------------------------------------------
 
 template <int RPT>
-__global__ void __launch_bounds__ (QR_THREADS) k_factorize (const QrTask *tasks, const QrRef *refs)
+__global__ void __launch_bounds__ (QR_THREADS, 2) k_factorize (const QrTask *tasks, const QrRef *refs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem [] ;
     factorize_panel<RPT> (tasks [refs [blockIdx.x].task].u.panel, smem) ;
@@ -500,6 +511,185 @@ static size_t kernel_lds_bytes (int kid)
     return 2 * QR_PACK_TILE * sizeof (int) ;
 }
 
+// -----------------------------------------------------------------------------
+// persistent work-queue kernel
+// -----------------------------------------------------------------------------
+//
+// One launch runs a whole engine call.  The queue holds the (task, block) pairs in
+// a topological order of their dependencies.  A resident workgroup draws the
+// next ticket, waits until the counter its task depends on has reached the
+// value recorded in the entry, runs the task, makes its stores visible
+// device-wide and adds one to the task's own counter.  Whoever holds ticket q
+// only ever waits for entries with smaller tickets, all of which are finished
+// or held by running workgroups, so the queue cannot deadlock whatever the
+// number of resident workgroups.  Every spin is bounded: when one runs out the
+// error word is set and every workgroup leaves at its next check.
+
+#define QR_SPIN_LIMIT (1u << 22)
+#define QR_QUEUE_LDS_TASK_BYTES ((256 + 32) * VS_LD * 8 + 256 * 4)     // apply_block<16>, the largest
+
+// Out-of-line bodies for the queue kernel: inlined into one kernel, the eight task variants
+// are register-allocated together and spill; as separate functions each keeps its own budget.
+// Arguments of a device function arrive in vector registers and the compiler no longer knows
+// that they are the same in every lane; readfirstlane puts the task fields back into scalar
+// registers (the descriptor is then read with scalar loads), so that the bodies compile as
+// they do inside a kernel.
+__device__ __forceinline__ int uni (int x) { return __builtin_amdgcn_readfirstlane (x) ; }
+template <class T> __device__ __forceinline__ T *uni_ptr (T *p)
+{
+    unsigned long long v = (unsigned long long) p ;
+    unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane ((int) (unsigned) v) ;
+    unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane ((int) (unsigned) (v >> 32)) ;
+    return (T *) (((unsigned long long) hi << 32) | lo) ;
+}
+// The LDS array is named again inside each body rather than passed in: a pointer argument would
+// be a generic pointer and every LDS access through it a flat access.
+template <int RPT>
+__device__ __attribute__((noinline)) void pq_factorize (const QrPanelTask &t)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem [] ;
+    factorize_panel<RPT> (*uni_ptr (&t), smem) ;
+}
+template <int MT>
+__device__ __attribute__((noinline)) void pq_apply (const QrPanelTask &t, const int blk)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem [] ;
+    apply_block<MT> (*uni_ptr (&t), uni (blk), smem) ;
+}
+
+__device__ __forceinline__ int queue_load (const int *p)
+{
+    return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
+}
+
+__global__ void __launch_bounds__ (QR_THREADS, 2)
+k_persistent (const QrTask *tasks, const QrQueueRef *refs, int nrefs, int *counters)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem [] ;
+    // two queue words live behind the largest task's LDS needs (no static LDS: it would sit in
+    // front of the dynamic array and shift its base)
+    int &sh_ticket = *reinterpret_cast<int *>(smem + QR_QUEUE_LDS_TASK_BYTES) ;
+    int &sh_ok = *reinterpret_cast<int *>(smem + QR_QUEUE_LDS_TASK_BYTES + 4) ;
+#ifdef PQ_STATS
+    unsigned long long t_wait = 0, t_run [3] = {0, 0, 0}, t_pub = 0, n_run = 0 ;
+    unsigned long long t_begin = __builtin_amdgcn_s_memtime ( ) ;
+#endif
+    for ( ; ; )
+    {
+#ifdef PQ_STATS
+        unsigned long long s0 = __builtin_amdgcn_s_memtime ( ) ;
+#endif
+        __syncthreads ( ) ;         // everybody is done with smem and sh_* of the previous task
+        if (threadIdx.x == 0)
+        {
+            int ok = 0 ;
+            int q = nrefs ;
+            if (queue_load (counters + QR_QUEUE_ERROR) == 0)
+                q = __hip_atomic_fetch_add (counters + QR_QUEUE_HEAD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
+            if (q < nrefs)
+            {
+                const QrQueueRef r = refs [q] ;
+                ok = 1 ;
+                if (r.need > 0)
+                {
+                    unsigned spins = 0 ;
+                    while (queue_load (counters + QR_QUEUE_FIRST + r.wait_ctr) < r.need)
+                    {
+                        __builtin_amdgcn_s_sleep (8) ;
+                        if ((++spins & 1023u) == 0 && queue_load (counters + QR_QUEUE_ERROR) != 0) { ok = 0 ; break ; }
+                        if (spins > QR_SPIN_LIMIT)
+                        {
+                            __hip_atomic_store (counters + QR_QUEUE_ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
+                            ok = 0 ;
+                            break ;
+                        }
+                    }
+                    // what the finished tasks wrote must not be served from this CU's stale L1 lines
+                    __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent") ;
+                    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory") ;
+                }
+            }
+            sh_ticket = q ;
+            sh_ok = ok ;
+        }
+        __syncthreads ( ) ;
+        const int q = sh_ticket ;
+#ifdef PQ_STATS
+        unsigned long long s1 = __builtin_amdgcn_s_memtime ( ) ;
+        t_wait += s1 - s0 ;
+        if (q >= nrefs || !sh_ok)
+        {
+            if (threadIdx.x == 0)
+            {
+                unsigned long long *st = (unsigned long long *) (counters + 1024) ;    // diagnostic build: counters has room
+                atomicAdd (st + 0, t_wait) ; atomicAdd (st + 1, t_run [0]) ; atomicAdd (st + 2, t_run [1]) ;
+                atomicAdd (st + 3, t_run [2]) ; atomicAdd (st + 4, t_pub) ; atomicAdd (st + 5, n_run) ;
+                atomicAdd (st + 6, __builtin_amdgcn_s_memtime ( ) - t_begin) ;
+            }
+            return ;
+        }
+#else
+        if (q >= nrefs || !sh_ok) return ;          // queue drained, or an error was raised
+#endif
+        const QrQueueRef r = refs [q] ;
+        const QrTask &t = tasks [r.task] ;
+        switch (t.type)
+        {
+            case QR_TASK_FACTORIZE:
+                switch (t.tier)
+                {
+                    case 0:  pq_factorize<4>  (t.u.panel) ; break ;
+                    case 1:  pq_factorize<8>  (t.u.panel) ; break ;
+                    case 2:  pq_factorize<16> (t.u.panel) ; break ;
+                    default: pq_factorize<32> (t.u.panel) ; break ;
+                }
+                break ;
+            case QR_TASK_APPLY:
+                switch (t.tier)
+                {
+                    case 0:  pq_apply<2>  (t.u.panel, r.blk) ; break ;
+                    case 1:  pq_apply<4>  (t.u.panel, r.blk) ; break ;
+                    case 2:  pq_apply<8>  (t.u.panel, r.blk) ; break ;
+                    default: pq_apply<16> (t.u.panel, r.blk) ; break ;
+                }
+                break ;
+            case QR_TASK_SASSEMBLE:
+                sassemble (t.u.sasm) ;
+                break ;
+            default:
+                packassemble (t.u.pack, smem) ;
+                break ;
+        }
+        // publish: every wave drains its stores, then one lane releases and signals
+        asm volatile ("s_waitcnt vmcnt(0)" ::: "memory") ;
+        __syncthreads ( ) ;
+#ifdef PQ_STATS
+        unsigned long long s2 = __builtin_amdgcn_s_memtime ( ) ;
+        t_run [t.type == QR_TASK_FACTORIZE ? 0 : (t.type == QR_TASK_APPLY ? 1 : 2)] += s2 - s1 ; n_run++ ;
+#endif
+        if (threadIdx.x == 0)
+        {
+#ifndef ABL_NOREL
+            __builtin_amdgcn_fence (__ATOMIC_RELEASE, "agent") ;
+#endif
+            asm volatile ("s_waitcnt vmcnt(0)" ::: "memory") ;
+            __hip_atomic_fetch_add (counters + QR_QUEUE_FIRST + r.signal_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
+        }
+#ifdef PQ_STATS
+        t_pub += __builtin_amdgcn_s_memtime ( ) - s2 ;
+#endif
+    }
+}
+
+extern "C" hipError_t qr_launch_persistent (const QrTask *d_tasks, const QrQueueRef *d_refs, int nrefs,
+    int *d_counters, int nworkgroups, hipStream_t stream)
+{
+    if (nrefs <= 0) return hipSuccess ;
+    hipLaunchKernelGGL (k_persistent, dim3 (nworkgroups), dim3 (QR_THREADS), QR_QUEUE_LDS_TASK_BYTES + 16, stream,
+        d_tasks, d_refs, nrefs, d_counters) ;
+    return hipGetLastError ( ) ;
+}
+
 // Launch nrefs workgroups of kernel id kid: workgroup b runs (task, block) = d_refs [b].
 extern "C" hipError_t qr_launch_tasks (int kid, const QrTask *d_tasks, const QrRef *d_refs, int nrefs, hipStream_t stream)
 {
@@ -525,6 +715,9 @@ extern "C" hipError_t qr_launch_tasks (int kid, const QrTask *d_tasks, const QrR
 extern "C" hipError_t qr_kernels_init (void)
 {
     // dynamic LDS above 64 KB needs an explicit opt-in on HIP
-    return hipFuncSetAttribute ((const void *) k_apply<16>,
+    hipError_t e = hipFuncSetAttribute ((const void *) k_apply<16>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int) kernel_lds_bytes (7)) ;
+    if (e != hipSuccess) return e ;
+    return hipFuncSetAttribute ((const void *) k_persistent,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int) (QR_QUEUE_LDS_TASK_BYTES + 16)) ;
 }

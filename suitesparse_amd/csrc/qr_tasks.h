@@ -74,6 +74,21 @@ struct QrRef
     int32_t blk;                // column block within an apply task, else 0
 };
 
+// Entry of the persistent work queue: the workgroup that draws ticket q runs refs[q] once the
+// counter wait_ctr has reached `need`, then adds one to signal_ctr.
+struct QrQueueRef
+{
+    int32_t task;
+    int32_t blk;
+    int32_t wait_ctr;
+    int32_t need;
+    int32_t signal_ctr;
+};
+
+#define QR_QUEUE_HEAD   0       // counters[0]: next ticket
+#define QR_QUEUE_ERROR  1       // counters[1]: nonzero after a spin ran out (no task hangs the device)
+#define QR_QUEUE_FIRST  2       // counters[2 + c]: arrivals at counter c
+
 struct QrTask
 {
     int32_t type;               // QrTaskType

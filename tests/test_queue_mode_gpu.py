@@ -1,0 +1,71 @@
+"""The persistent work-queue kernel runs the same task list as the per-round launches: its
+results must be bit-identical to theirs, for dense batches and for the sparse path."""
+import numpy as np
+import pytest
+
+import suitesparse_amd as ss
+from suitesparse_amd import _lib, problems, spqr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def queue_mode():
+    L = _lib.lib()
+
+    def set_mode(m):
+        L.gpuqr_set_mode(m)
+    yield set_mode
+    L.gpuqr_set_mode(0)
+
+
+def _dense(mats):
+    fronts = []
+    for k, A in enumerate(mats):
+        m, n = A.shape
+        f = ss.Front(k, ss.EMPTY, m, n)
+        f.F = np.ascontiguousarray(A)
+        f.cpuR = np.zeros((min(m, n), n), dtype=np.float64)
+        fronts.append(f)
+    stats = ss.QREngineStats()
+    assert ss.GPUQREngine(0, fronts, len(fronts), stats=stats) == ss.QRENGINE_SUCCESS
+    return [np.array(f.cpuR) for f in fronts], stats
+
+
+def test_dense_batch_bitwise_equal(queue_mode):
+    rng = np.random.default_rng(11)
+    shapes = [(1, 1), (40, 70), (96, 32), (300, 100), (257, 257), (1024, 384), (700, 900), (33, 31)]
+    mats = [rng.standard_normal((m, n)) for m, n in shapes]
+    queue_mode(0)
+    R0, s0 = _dense(mats)
+    queue_mode(1)
+    R1, s1 = _dense(mats)
+    assert s1.numLaunches == 1 and s0.numLaunches > 1
+    assert s0.flopsActual == s1.flopsActual
+    for a, b in zip(R0, R1):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("grid,leaf", [((40, 40), 4), ((9, 9, 9), 2)])
+def test_sparse_bitwise_equal(queue_mode, grid, leaf):
+    A = problems.stacked_ls(grid)
+    sym = spqr.analyze(A, problems.nested_dissection(grid, leaf=leaf), relax=20, gpuMemorySize=2**34)
+    queue_mode(0)
+    r0 = spqr.factorize(sym, A)
+    queue_mode(1)
+    r1 = spqr.factorize(sym, A)
+    assert r0.rank == r1.rank == sym.n
+    assert (r0.R != r1.R).nnz == 0
+
+
+def test_staged_sparse_in_queue_mode(queue_mode):
+    grid = (40, 40)
+    A = problems.stacked_ls(grid)
+    Q = problems.nested_dissection(grid, leaf=4)
+    one = spqr.factorize(spqr.analyze(A, Q, relax=0, gpuMemorySize=2**34), A)
+    queue_mode(1)
+    sym = spqr.analyze(A, Q, relax=0, gpuMemorySize=10_700_000)
+    assert sym.numStages > 1
+    res = spqr.factorize(sym, A)
+    assert res.numStagesRun == sym.numStages
+    assert (one.R != res.R).nnz == 0
