@@ -37,15 +37,16 @@ typedef __attribute__((address_space(1))) const int gcint ;
 // local row -> front row map of a panel task (in LDS)
 // -----------------------------------------------------------------------------
 
-__device__ __forceinline__ void build_rowmap (const QrPanelTask &t, int *rowmap, int cap)
+// Entries past the task's K rows get `fill`.
+__device__ __forceinline__ void build_rowmap (const QrPanelTask &t, int *rowmap, int cap, int fill = -1)
 {
     for (int r = threadIdx.x ; r < cap ; r += QR_THREADS)
     {
-        int g = -1, acc = 0 ;
+        int g = fill, acc = 0 ;
         for (int s = 0 ; s < t.nseg ; s++)
         {
             int n = t.seg_n [s] ;
-            if (g < 0 && r < acc + n) g = t.seg_row [s] + (r - acc) ;
+            if (r >= acc && r < acc + n) g = t.seg_row [s] + (r - acc) ;
             acc += n ;
         }
         rowmap [r] = g ;
@@ -275,14 +276,47 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
 // LDS.  Each of the 4 waves then walks 16-column slabs of [c_begin,c_end).  A
 // slab (K x 16) lives in registers as MT = K/16 MFMA C/D tiles.  For
 // v_mfma_f64_16x16x4_f64 the C/D tile register i of lane l is element
-// (row 4i + l/16, col l%16), which is exactly the B-operand layout of the
-// 4-row slice 4i..4i+3, so the same registers serve as
+// (m = 4i + l/16, n = l%16), which is exactly the B-operand layout of the
+// 4-deep slice i, so the same registers serve as
 //   B operand of  W  = V' A      (32 x 16, contraction over the K rows)
 //   accumulator of A -= V (T' W) (contraction over the 32 reflector columns)
 // and the slab makes one trip from HBM and back with no LDS staging of A.
+//
+// Memory side: 8 bytes per lane (one element) moves a slab at about half the
+// rate of 16 bytes per lane, so a lane loads two neighbouring columns of one
+// row: lane l covers row l/8 of an 8-row group and columns 2(l%8), 2(l%8)+1 of
+// the slab (8 rows x 128 B per instruction).  The MFMA needs one column per
+// lane, so lanes l and l^8 trade one element each (one DPP row rotation by 8):
+// afterwards lane l holds rows 2(l/16) and 2(l/16)+1 of the group in column
+// 2(l%8) + (l/8)%2.  Neither the order of the rows inside a tile nor the order
+// of the columns inside a slab matters to the arithmetic as long as V is read
+// in the same row order, so tile register i of lane l stands for
+//   row  16 mt + 8 (i/2) + 2 (l/16) + i%2,   column slot l%16.
 // LDS row stride 34 doubles keeps the A-operand reads of step 3 conflict free.
 
 #define VS_LD 34
+
+typedef double d2 __attribute__((ext_vector_type(2))) ;
+typedef __attribute__((address_space(1))) d2 __attribute__((aligned(8))) gd2 ;  // rows of odd fn are only 8-byte aligned
+
+// old in the lanes whose bank (group of 4 lanes within a row of 16) is not in BANKS, elsewhere
+// src of the lane 8 further round the row
+template <int BANKS> __device__ __forceinline__ double row_ror8_merge (double old, double src)
+{
+    int lo = __builtin_amdgcn_update_dpp (__double2loint (old), __double2loint (src), 0x128, 0xf, BANKS, false) ;
+    int hi = __builtin_amdgcn_update_dpp (__double2hiint (old), __double2hiint (src), 0x128, 0xf, BANKS, false) ;
+    return __hiloint2double (hi, lo) ;
+}
+
+// (row r, columns c and c+1) per lane  <->  (rows r_even and r_even+1, one column) per lane; the
+// exchange is its own inverse
+__device__ __forceinline__ d2 pair_exchange (d2 v)
+{
+    d2 o ;
+    o.x = row_ror8_merge<0xC> (v.x, v.y) ;
+    o.y = row_ror8_merge<0x3> (v.y, v.x) ;
+    return o ;
+}
 
 template <int MT>
 __device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk, char *smem)
@@ -297,9 +331,54 @@ __device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk
     gdouble *F = (gdouble *) t.F ;
     gcdouble *VT = (gcdouble *) t.VT ;
 
-    build_rowmap (t, rowmap, MT*16) ;
+    // rows past K point at the task's first row: loads through them stay in bounds, what they
+    // bring meets zero rows of V, and nothing is stored through them
+    build_rowmap (t, rowmap, MT*16, t.seg_row [0]) ;
     __syncthreads ( ) ;
 
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane (tid >> 6) ;    // wave: a scalar
+    const int lr = lane >> 4, lc = lane & 15 ;
+    const int l8 = lane >> 3 ;                  // memory side: row within an 8-row group
+    const int j2 = (lane & 7) * 2 ;             // memory side: first of the lane's two columns
+    const int pi_lc = 8*(lc >> 3) + 2*(lc & 3) + ((lc >> 2) & 1) ;     // tile row held by MFMA row lc
+    const int c_begin = t.c_begin + blk * t.cb_cols ;
+    const int c_end = (c_begin + t.cb_cols < t.c_end) ? (c_begin + t.cb_cols) : t.c_end ;
+    const int nslab = (c_end - c_begin + 15) >> 4 ;
+
+    // Software pipeline over the wave's slabs: while step 3 finishes tile mt of
+    // the current slab, that tile is stored and the same registers are refilled
+    // with tile mt of the wave's next slab, so the loads and stores of one slab
+    // travel while the matrix pipe works on another.  What a load brings stays
+    // in memory order until step 1 of its slab needs it.
+    //
+    // Loads are unconditional, so that none of them sits in a branch with a wait
+    // behind it: a lane whose columns lie (partly) past c_end reads the last two
+    // columns before c_end instead (c_end - 2 >= c_begin - 1 >= 31 is a column of
+    // the same row), rows past K read the task's first row.  The stray values are
+    // finite entries of the front, each column slot is computed independently
+    // and rows past K meet zero rows of V, so they change nothing that is stored.
+    d2 A [MT][2] ;
+    {
+        const int slab0 = (wave < nslab) ? wave : 0 ;
+        const int col = c_begin + slab0*16 + j2 ;
+        const int lcol = (col < c_end - 2) ? col : (c_end - 2) ;
+        #pragma unroll
+        for (int mt = 0 ; mt < MT ; mt++)
+        {
+            #pragma unroll
+            for (int h = 0 ; h < 2 ; h++)
+            {
+                const int r = mt*16 + 8*h + l8 ;
+#ifdef ABL_NOMEM
+                A [mt][h] = (d2) {(double) (r + col), 1.0} ;
+#else
+                A [mt][h] = *(gd2 *) (F + (size_t) rowmap [r] * ld + lcol) ;
+#endif
+            }
+        }
+    }
+
+    // V and T go to LDS while the first slab is on its way
     for (int idx = tid ; idx < MT*16*32 ; idx += QR_THREADS)
     {
         int r = idx >> 5, c = idx & 31 ;
@@ -318,42 +397,14 @@ __device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk
     }
     __syncthreads ( ) ;
 
-    const int lane = tid & 63, wave = tid >> 6 ;
-    const int lr = lane >> 4, lc = lane & 15 ;
-    const int c_begin = t.c_begin + blk * t.cb_cols ;
-    const int c_end = (c_begin + t.cb_cols < t.c_end) ? (c_begin + t.cb_cols) : t.c_end ;
-    const int nslab = (c_end - c_begin + 15) >> 4 ;
-
-    // Software pipeline over the wave's slabs: while step 3 finishes tile mt of
-    // the current slab, that tile is stored and the same registers are refilled
-    // with tile mt of the wave's next slab, so the loads and stores of one slab
-    // travel while the matrix pipe works on another.
-    v4f64 A [MT] ;
-    {
-        const int col = c_begin + wave*16 + lc ;
-        const bool cvalid = (wave < nslab) && (col < c_end) ;
-        #pragma unroll
-        for (int mt = 0 ; mt < MT ; mt++)
-        {
-            #pragma unroll
-            for (int i = 0 ; i < 4 ; i++)
-            {
-                int r = mt*16 + 4*i + lr ;
-#ifdef ABL_NOMEM
-                A [mt][i] = (double) (r + col) ;
-#else
-                A [mt][i] = (cvalid && r < K) ? F [(size_t) rowmap [r] * ld + col] : 0.0 ;
-#endif
-            }
-        }
-    }
-
     for (int slab = wave ; slab < nslab ; slab += 4)
     {
-        const int col = c_begin + slab*16 + lc ;
-        const bool cvalid = col < c_end ;
-        const int ncol = col + 64 ;
-        const bool nvalid = (slab + 4 < nslab) && (ncol < c_end) ;
+        const int col = c_begin + slab*16 + j2 ;
+        const bool v0 = col < c_end, v1 = col + 1 < c_end ;
+        // after its last slab a wave fetches that slab again (from L2, it has just been written)
+        // rather than branch round 2 MT loads
+        const int ncol = (slab + 4 < nslab) ? (col + 64) : col ;
+        const int nlcol = (ncol < c_end - 2) ? ncol : (c_end - 2) ;
 
         // step 1: W = V' A, two 16-row tiles of W (two independent accumulation chains)
         v4f64 W0 = {0,0,0,0}, W1 = {0,0,0,0} ;
@@ -361,12 +412,19 @@ __device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk
         for (int mt = 0 ; mt < MT ; mt++)
         {
             #pragma unroll
-            for (int i = 0 ; i < 4 ; i++)
+            for (int h = 0 ; h < 2 ; h++)
             {
-                int r = mt*16 + 4*i + lr ;
-                double b = A [mt][i] ;
-                W0 = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [r][lc],      b, W0, 0, 0, 0) ;
-                W1 = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [r][16 + lc], b, W1, 0, 0, 0) ;
+                d2 v = A [mt][h] ;
+                v.x = v1 ? v.x : v.y ;      // last column of an odd width: the load was moved one column back
+                A [mt][h] = pair_exchange (v) ;
+                #pragma unroll
+                for (int e = 0 ; e < 2 ; e++)
+                {
+                    const int r = mt*16 + 8*h + 2*lr + e ;
+                    const double b = A [mt][h][e] ;
+                    W0 = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [r][lc],      b, W0, 0, 0, 0) ;
+                    W1 = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [r][16 + lc], b, W1, 0, 0, 0) ;
+                }
             }
         }
 
@@ -386,40 +444,39 @@ __device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk
         X0 = -X0 ; X1 = -X1 ;
 
         // step 3: A += V (-X), tile by tile; store the tile, fetch its successor.
-        // The opaque copy of the lane row makes the compiler recompute the
-        // addresses from the row map instead of keeping 64 address pairs alive
-        // across the MFMA section.
-        int lr_st = lr ;
-        asm volatile ("" : "+v" (lr_st)) ;
+        // The opaque copy of the lane's memory row makes the compiler recompute
+        // the addresses from the row map instead of keeping them alive across
+        // the MFMA section.
+        int l8_st = l8 ;
+        asm volatile ("" : "+v" (l8_st)) ;
         #pragma unroll
         for (int mt = 0 ; mt < MT ; mt++)
         {
-            v4f64 acc = A [mt] ;
+            v4f64 acc = {A [mt][0][0], A [mt][0][1], A [mt][1][0], A [mt][1][1]} ;
             #pragma unroll
             for (int q = 0 ; q < 4 ; q++)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [mt*16 + lc][4*q + lr], X0 [q], acc, 0, 0, 0) ;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [mt*16 + pi_lc][4*q + lr], X0 [q], acc, 0, 0, 0) ;
             #pragma unroll
             for (int q = 0 ; q < 4 ; q++)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [mt*16 + lc][16 + 4*q + lr], X1 [q], acc, 0, 0, 0) ;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [mt*16 + pi_lc][16 + 4*q + lr], X1 [q], acc, 0, 0, 0) ;
             #pragma unroll
-            for (int i = 0 ; i < 4 ; i++)
+            for (int h = 0 ; h < 2 ; h++)
             {
-                int r = mt*16 + 4*i + lr_st ;
+                const int r = mt*16 + 8*h + l8_st ;
+                d2 o = {acc [2*h], acc [2*h + 1]} ;
+                o = pair_exchange (o) ;
+                gdouble *rowp = F + (size_t) rowmap [r] * ld ;
+#ifdef ABL_NOMEM
+                if (o.x == 1.2345e-300) rowp [col] = o.y ;
+                A [mt][h] = (d2) {o.x + 1.0, o.y + 1.0} ;
+#else
                 if (r < K)
                 {
-                    gdouble *rowp = F + (size_t) rowmap [r] * ld ;
-#ifdef ABL_NOMEM
-                    if (acc [i] == 1.2345e-300) rowp [col] = acc [i] ;
-                    A [mt][i] = acc [i] + 1.0 ;
-#else
-                    if (cvalid) rowp [col] = acc [i] ;
-                    A [mt][i] = nvalid ? rowp [ncol] : 0.0 ;
+                    if (v1)      *(gd2 *) (rowp + col) = o ;
+                    else if (v0) rowp [col] = o.x ;
+                }
+                A [mt][h] = *(gd2 *) (rowp + nlcol) ;
 #endif
-                }
-                else
-                {
-                    A [mt][i] = 0.0 ;
-                }
             }
         }
     }
