@@ -57,15 +57,22 @@ __device__ __forceinline__ void build_rowmap (const QrPanelTask &t, int *rowmap,
 // factorize_panel
 // -----------------------------------------------------------------------------
 //
-// Thread (rg, c), rg = tid/32 in 0..7, c = tid%32, keeps rows rg, rg+8, ... of
-// column c in registers (RPT of them).  Per column k: the two lanes per wave
-// that own column k publish it to LDS with their partial sum of squares, every
-// thread forms the normalised Householder vector v (v_k = 1), computes its
-// share of v'A, the 8 row groups are reduced with one cross-half shuffle and a
-// 4-entry LDS sum, and the rank-1 update is applied in registers.  Two
-// barriers per column.  Columns j < k hold v_j, so the same dot products give
-// -tau_k v_j'v_k, from which T is built (T(0:k-1,k) = T(0:k-1,0:k-1) z(0:k-1),
-// the recurrence of factorize_vt.cu:397-410 and spqr_larftb.cpp:13-22).
+// Each of the 4 waves owns 8 of the 32 panel columns.  Lane l of a wave stands
+// for column cl = l/8 of the wave and row group rg = l%8, and keeps rows rg,
+// rg+8, ... of its column in registers (RPT of them).  A sum over the rows of
+// one column is then a sum over 8 neighbouring lanes: three DPP steps, no LDS
+// and no barrier.  Per column k:
+//   every lane reads the normalised Householder vector v_k (v_kk = 1, zeros
+//   above) from LDS, forms its share of v_k'a_c, reduces it over its 8 lanes,
+//   and updates its column: a_c -= tau (v_k'a_c) v_k;
+//   the 8 lanes of column k+1 then hold that column's final values, so they
+//   compute its reflector at once (sigma over 8 lanes, the scalar part, the
+//   normalised vector) and publish it to LDS for the next step.
+// One barrier per column.  Columns j < k hold v_j, so the same dot products
+// give Z(j,k) = -tau_k v_j'v_k, from which a wave that is off the critical
+// path builds column k of T during the next step:
+// T(0:k-1,k) = T(0:k-1,0:k-1) Z(0:k-1,k), T(k,k) = tau_k (the recurrence of
+// factorize_vt.cu:397-410 and spqr_larftb.cpp:13-22).
 //
 // Householder convention (restated from factorize_vt.cu:272-293, but with v
 // scaled to a unit head so that V1 fits the strictly-lower part of the VT
@@ -76,155 +83,193 @@ __device__ __forceinline__ void build_rowmap (const QrPanelTask &t, int *rowmap,
 struct FactorizeLds
 {
     int    rowmap [QR_MAX_K] ;
-    double vbuf   [2][QR_MAX_K] ;
-    double sig    [8] ;
-    double x1 ;
-    double dpart  [4][32] ;
-    double Z      [32][33] ;
+    double vbuf   [2][QR_MAX_K] ;   // double buffered: v_k is read while v_{k+1} is written
     double tau    [32] ;
+    double Z      [32][33] ;
+    double T      [32][33] ;
 } ;
 
-// T of the compact WY form from the by-products of the panel loop: Z(i,k) = -tau_k v_i'v_k for
-// i < k, tau on the diagonal; T(0:k-1,k) = T(0:k-1,0:k-1) Z(0:k-1,k).  Lane j owns row j of T in
-// registers; T(j,i) = 0 for i < j, so the unmasked sum is the triangular product.  Kept out of
-// line so that its 32 row registers do not add to the register budget of the panel loop.
-__device__ __attribute__((noinline)) void build_t (FactorizeLds &L, const int kmax, const int w, gdouble *VT, const int tid)
+template <int CTRL> __device__ __forceinline__ double dpp_move (double x)
 {
-    double trow [32] ;
-    #pragma unroll
-    for (int i = 0 ; i < 32 ; i++) trow [i] = 0 ;
-    #pragma unroll
-    for (int k = 0 ; k < 32 ; k++)
-    {
-        if (k < kmax)
-        {
-            double acc0 = 0, acc1 = 0 ;
-            #pragma unroll
-            for (int i = 0 ; i + 1 < k ; i += 2)
-            {
-                acc0 += trow [i]   * L.Z [i][k] ;
-                acc1 += trow [i+1] * L.Z [i+1][k] ;
-            }
-            if (k & 1) acc0 += trow [k-1] * L.Z [k-1][k] ;
-            trow [k] = (tid < k) ? (acc0 + acc1) : ((tid == k) ? L.tau [k] : 0.0) ;
-        }
-    }
-    #pragma unroll
-    for (int i = 0 ; i < 32 ; i++)
-        if (i >= tid && tid < w && i < w) VT [tid*32 + i] = trow [i] ;
+    int lo = __builtin_amdgcn_update_dpp (0, __double2loint (x), CTRL, 0xf, 0xf, true) ;
+    int hi = __builtin_amdgcn_update_dpp (0, __double2hiint (x), CTRL, 0xf, 0xf, true) ;
+    return __hiloint2double (hi, lo) ;
 }
 
-// The 8 Householder steps k = 8*IK .. 8*IK+7.  With rows dealt to threads as
+// sum over each group of 8 neighbouring lanes, result in all 8
+__device__ __forceinline__ double sum8 (double x)
+{
+    x += dpp_move<0xB1> (x) ;       // quad_perm [1,0,3,2]
+    x += dpp_move<0x4E> (x) ;       // quad_perm [2,3,0,1]
+    x += dpp_move<0x141> (x) ;      // row_half_mirror: lane i <-> 7-i of each 8
+    return x ;
+}
+
+// Column kc of T, by the lower 32 lanes of one wave (lane j: row j).  Z(i,kc) = 0 for i >= kc and
+// T(j,i) = 0 for i < j (both arrays start as zeros), so the sums need no masks.
+__device__ __forceinline__ void t_column (FactorizeLds &L, const int kc, const int lane)
+{
+    if (lane < 32)
+    {
+        double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0 ;
+        for (int i = 0 ; i < kc ; i += 4)
+        {
+            acc0 += L.T [lane][i]   * L.Z [i][kc] ;
+            acc1 += L.T [lane][i+1] * L.Z [i+1][kc] ;
+            acc2 += L.T [lane][i+2] * L.Z [i+2][kc] ;
+            acc3 += L.T [lane][i+3] * L.Z [i+3][kc] ;
+        }
+        L.T [lane][kc] = (lane < kc) ? ((acc0 + acc1) + (acc2 + acc3)) : ((lane == kc) ? L.tau [kc] : 0.0) ;
+    }
+}
+
+// The 8 lanes of column k1 (all of them active, nobody else) make its reflector and publish it:
+// vb[r] = 0 above row k1, 1 at k1, a_r/v1 below, for the rows of slots >= I0; returns R(k1,k1).
+template <int RPT>
+__device__ __forceinline__ double make_reflector
+(
+    const double (&a) [RPT], FactorizeLds &L, const int k1, const int i0, const int rg
+)
+{
+    double part = 0, x1 = 0 ;
+    #pragma unroll
+    for (int i = 0 ; i < RPT ; i++)
+    {
+        const int r = rg + 8*i ;
+        const double x = a [i] ;
+        if (r > k1) part += x*x ;
+        else if (r == k1) x1 = x ;
+    }
+    const double sigma = sum8 (part) ;
+    x1 = sum8 (x1) ;                // one lane holds it, the others add zeros
+    // The scalar part sits on the critical path of every column, so it is built from the
+    // hardware reciprocal and reciprocal square root seeds with two Newton steps each (a
+    // dozen dependent operations) instead of the library square root and two divisions.
+    double s, tau, inv ;
+    if (sigma <= HOUSE_EPS)
+    {
+        s = x1 ; tau = 0 ; inv = 0 ;
+    }
+    else
+    {
+        const double n2 = fma (x1, x1, sigma) ;
+        double y = __builtin_amdgcn_rsq (n2) ;                  // ~ 1/s
+        y = fma (0.5 * y, fma (-n2 * y, y, 1.0), y) ;
+        y = fma (0.5 * y, fma (-n2 * y, y, 1.0), y) ;
+        s = n2 * y ;
+        s = fma (fma (-s, s, n2), 0.5 * y, s) ;                 // s = sqrt (n2)
+        const double q = x1 + s ;                               // used when x1 > 0: no cancellation
+        double rq = __builtin_amdgcn_rcp (q) ;
+        rq = fma (rq, fma (-q, rq, 1.0), rq) ;
+        rq = fma (rq, fma (-q, rq, 1.0), rq) ;
+        const double v1 = (x1 <= 0) ? (x1 - s) : (-sigma * rq) ;
+        tau = -v1 * y ;
+        inv = __builtin_amdgcn_rcp (v1) ;
+        inv = fma (inv, fma (-v1, inv, 1.0), inv) ;
+        inv = fma (inv, fma (-v1, inv, 1.0), inv) ;
+    }
+    double *vb = L.vbuf [k1 & 1] ;
+    #pragma unroll
+    for (int i = 0 ; i < RPT ; i++)
+    {
+        const int r = rg + 8*i ;
+        if (i >= i0) vb [r] = (r > k1) ? a [i] * inv : ((r == k1) ? 1.0 : 0.0) ;
+    }
+    if (rg == 0) L.tau [k1] = tau ;
+    return s ;
+}
+
+// The 8 Householder steps k = 8*IK .. 8*IK+7.  With rows dealt to lanes as
 // r = rg + 8*i, the register slot of the pivot row (i = IK) is a compile-time
 // constant inside this function: slots i < IK lie entirely above the pivot row
-// and are skipped, slots i > IK lie entirely below it and need no masks; only
-// slot IK is compared against the runtime row group of the pivot.
+// and are skipped (v is zero there).
 template <int RPT, int IK>
 __device__ __forceinline__ void house_steps
 (
-    double (&a) [RPT], FactorizeLds &L, const int kmax, const int rg, const int c, const int tid
+    double (&a) [RPT], double &s_cur, FactorizeLds &L, const int kmax, const int rg, const int c,
+    const int wave, const int lane
 )
 {
     if constexpr (IK < RPT)
     {
-        const int wave = tid >> 6 ;
         for (int rgk = 0 ; rgk < 8 ; rgk++)
         {
             const int k = 8*IK + rgk ;
             if (k >= kmax) break ;
-            double *vb = L.vbuf [k & 1] ;    // double buffered: stragglers still read the other one
+            const int k1 = k + 1 ;
+            const int own1 = (k1 >> 3) & 3 ;            // the wave that owns column k+1: the critical one
+            if (k > 0 && wave == ((own1 + 2) & 3)) t_column (L, k - 1, lane) ;
 
-            // ---- owners of column k publish it and their share of sigma ----------
-            if (c == k)
-            {
-                double part = 0 ;
-                #pragma unroll
-                for (int i = IK ; i < RPT ; i++)
-                {
-                    const double x = a [i] ;
-                    if (i > IK || rg > rgk) { part += x*x ; vb [rg + 8*i] = x ; }
-                    else if (rg == rgk) { L.x1 = x ; }
-                }
-                L.sig [rg] = part ;
-            }
-            __syncthreads ( ) ;
+            const double *vb = L.vbuf [k & 1] ;
+            double v [RPT] ;
+            #pragma unroll
+            for (int i = IK ; i < RPT ; i++) v [i] = vb [rg + 8*i] ;
+            const double tau = L.tau [k] ;
 
-            const double sigma = ((L.sig [0] + L.sig [1]) + (L.sig [2] + L.sig [3]))
-                               + ((L.sig [4] + L.sig [5]) + (L.sig [6] + L.sig [7])) ;
-            const double x1 = L.x1 ;
-            double s, tau, inv ;
-            if (sigma <= HOUSE_EPS)
-            {
-                s = x1 ; tau = 0 ; inv = 0 ;
-            }
-            else
-            {
-                s = sqrt (x1*x1 + sigma) ;
-                const double v1 = (x1 <= 0) ? (x1 - s) : (-sigma / (x1 + s)) ;
-                tau = -v1 / s ;
-                inv = 1.0 / v1 ;
-            }
-
-            // ---- v'A over rows >= k ------------------------------------------------
-            double d = 0 ;
+            double d0 = 0, d1 = 0 ;
             #pragma unroll
             for (int i = IK ; i < RPT ; i++)
             {
-                double vr ;
-                if (i > IK) vr = vb [rg + 8*i] * inv ;
-                else        vr = (rg > rgk) ? vb [rg + 8*i] * inv : ((rg == rgk) ? 1.0 : 0.0) ;
-                d += vr * a [i] ;
+                if ((i - IK) & 1) d1 += v [i] * a [i] ; else d0 += v [i] * a [i] ;
             }
-            d += __shfl_xor (d, 32) ;
-            if ((tid & 63) < 32) L.dpart [wave][c] = d ;
-            __syncthreads ( ) ;
+            const double z = -tau * sum8 (d0 + d1) ;
 
-            const double z = -tau * ((L.dpart [0][c] + L.dpart [1][c]) + (L.dpart [2][c] + L.dpart [3][c])) ;
-            // v is read again from LDS rather than kept in registers (RPT more live values would
-            // push the 256-row variant past the budget of two waves per SIMD)
             if (c > k)
             {
                 #pragma unroll
-                for (int i = IK ; i < RPT ; i++)
-                {
-                    double vr ;
-                    if (i > IK) vr = vb [rg + 8*i] * inv ;
-                    else        vr = (rg > rgk) ? vb [rg + 8*i] * inv : ((rg == rgk) ? 1.0 : 0.0) ;
-                    a [i] += vr * z ;
-                }
+                for (int i = IK ; i < RPT ; i++) a [i] += v [i] * z ;
             }
             else if (c == k)
             {
+                // the column becomes R above and at the diagonal, v below it
                 #pragma unroll
                 for (int i = IK ; i < RPT ; i++)
                 {
-                    if (i > IK || rg > rgk) a [i] = vb [rg + 8*i] * inv ;
-                    else if (rg == rgk)     a [i] = s ;
+                    if (i > IK || rg > rgk) a [i] = v [i] ;
+                    else if (rg == rgk)     a [i] = s_cur ;
                 }
             }
             else if (rg == 0)
             {
                 L.Z [c][k] = z ;
             }
-            if (tid == 0) L.tau [k] = tau ;
+
+            if (wave == own1 && k1 < kmax)
+            {
+                if (c == k1) s_cur = make_reflector<RPT> (a, L, k1, (rgk == 7) ? IK + 1 : IK, rg) ;
+            }
+            __syncthreads ( ) ;
         }
     }
 }
 
+#ifdef FACT_STATS
+__device__ unsigned long long g_fact_stats [8] ;
+#define FACT_TICK(i) do { __syncthreads ( ) ; if (threadIdx.x == 0) { unsigned long long now = __builtin_amdgcn_s_memtime ( ) ; \
+    atomicAdd (&g_fact_stats [i], now - tick) ; tick = now ; } } while (0)
+#else
+#define FACT_TICK(i)
+#endif
+
 template <int RPT>
 __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *smem)
 {
+#ifdef FACT_STATS
+    unsigned long long tick = __builtin_amdgcn_s_memtime ( ) ;
+#endif
     FactorizeLds &L = *reinterpret_cast<FactorizeLds *>(smem) ;
     const int tid = threadIdx.x ;
-    const int c = tid & 31 ;
-    const int rg = tid >> 5 ;
+    const int lane = tid & 63 ;
+    const int wave = __builtin_amdgcn_readfirstlane (tid >> 6) ;    // a scalar: branches on it are uniform
+    const int rg = lane & 7 ;
+    const int c = 8*wave + (lane >> 3) ;
     const int K = t.K, w = t.w, ld = t.ld ;
     const int kmax = (K < w) ? K : w ;
     gdouble *F = (gdouble *) t.F ;
     gdouble *VT = (gdouble *) t.VT ;
 
     build_rowmap (t, L.rowmap, 8*RPT) ;
-    for (int i = tid ; i < 32*33 ; i += QR_THREADS) (&L.Z[0][0]) [i] = 0 ;
+    for (int i = tid ; i < 2*32*33 ; i += QR_THREADS) (&L.Z[0][0]) [i] = 0 ;     // Z and T
     __syncthreads ( ) ;
 
     double a [RPT] ;
@@ -235,10 +280,17 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
         a [i] = (r < K && c < w) ? F [(size_t) L.rowmap [r] * ld + t.col0 + c] : 0.0 ;
     }
 
-    house_steps<RPT, 0> (a, L, kmax, rg, c, tid) ;
-    house_steps<RPT, 1> (a, L, kmax, rg, c, tid) ;
-    house_steps<RPT, 2> (a, L, kmax, rg, c, tid) ;
-    house_steps<RPT, 3> (a, L, kmax, rg, c, tid) ;
+    double s_cur = 0 ;
+    if (wave == 0 && c == 0) s_cur = make_reflector<RPT> (a, L, 0, 0, rg) ;
+    __syncthreads ( ) ;
+
+    FACT_TICK (0) ;
+    house_steps<RPT, 0> (a, s_cur, L, kmax, rg, c, wave, lane) ;
+    FACT_TICK (1) ;
+    house_steps<RPT, 1> (a, s_cur, L, kmax, rg, c, wave, lane) ;
+    house_steps<RPT, 2> (a, s_cur, L, kmax, rg, c, wave, lane) ;
+    house_steps<RPT, 3> (a, s_cur, L, kmax, rg, c, wave, lane) ;
+    FACT_TICK (2) ;
 
     // ---- write back R (zeros below the diagonal), V2 in place, V1 to the VT tile ----
     #pragma unroll
@@ -259,13 +311,20 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
             }
         }
     }
+    FACT_TICK (3) ;
 
-    // ---- T (only when somebody will apply this panel) ------------------------
+    // ---- T (only when somebody will apply this panel): its last column, then the tile ----
     if (VT != NULL)
     {
+        if (wave == 0) t_column (L, kmax - 1, lane) ;
         __syncthreads ( ) ;
-        if (tid < 32) build_t (L, kmax, w, VT, tid) ;
+        for (int idx = tid ; idx < 32*32 ; idx += QR_THREADS)
+        {
+            const int r = idx >> 5, cc = idx & 31 ;
+            if (cc >= r && r < w && cc < w) VT [r*32 + cc] = L.T [r][cc] ;
+        }
     }
+    FACT_TICK (4) ;
 }
 
 // -----------------------------------------------------------------------------
