@@ -99,7 +99,14 @@ extern "C" size_t gpuqr_max_queue_size (size_t gpuMemorySize)
     return (q < min_queue) ? min_queue : q ;
 }
 
+static int64_t *find_staircase_ld (const double *F, int64_t fm, int64_t fn, int64_t ld) ;
+
 extern "C" int64_t *gpuqr_find_staircase (const double *F, int64_t fm, int64_t fn)
+{
+    return find_staircase_ld (F, fm, fn, fn) ;
+}
+
+static int64_t *find_staircase_ld (const double *F, int64_t fm, int64_t fn, int64_t ld)
 {
     // GPUQREngine_ExpertDense.cpp:196-217: Stair[j] is the last row of column
     // j holding a nonzero, never above the previous column's stair
@@ -110,7 +117,7 @@ extern "C" int64_t *gpuqr_find_staircase (const double *F, int64_t fm, int64_t f
     for (int64_t j = 0 ; j < fn ; j++)
     {
         int64_t i = fm - 1 ;
-        while (i > last && F [i*fn + j] == 0.0) i-- ;
+        while (i > last && F [i*ld + j] == 0.0) i-- ;
         Stair [j] = last = i ;
     }
     return Stair ;
@@ -204,7 +211,7 @@ struct Seg { int32_t row, n ; } ;
 // Emit all factorize/apply tasks of one front.  Returns the last round used.
 static int32_t plan_front
 (
-    Plan &plan, double *F, int64_t fm, int64_t fn, const int64_t *Stair,
+    Plan &plan, double *F, int64_t fm, int64_t fn, int64_t ld, const int64_t *Stair,
     int32_t start_round, bool emit
 )
 {
@@ -284,7 +291,7 @@ static int32_t plan_front
             st.t.type = QR_TASK_FACTORIZE ;
             st.t.tier = tier_of (fr.K) ;
             QrPanelTask &pt = st.t.u.panel ;
-            pt.F = F ; pt.VT = NULL ; pt.ld = (int32_t) fn ; pt.col0 = (int32_t) c0 ; pt.w = (int32_t) w ;
+            pt.F = F ; pt.VT = NULL ; pt.ld = (int32_t) ld ; pt.col0 = (int32_t) c0 ; pt.w = (int32_t) w ;
             pt.K = fr.K ; pt.nseg = fr.nseg ; pt.c_begin = pt.c_end = 0 ;
             for (int s = 0 ; s < fr.nseg ; s++) { pt.seg_row [s] = fr.segs [s].row ; pt.seg_n [s] = fr.segs [s].n ; }
             st.round = rF0 + fr.level ;
@@ -304,7 +311,7 @@ static int32_t plan_front
             // rounds of the previous panel), so one apply task per factorize task covers the whole
             // trailing width; the kernel cuts it into column blocks, one workgroup each.
             const int64_t t0 = p + 1 ;
-            int64_t bt = 4 ;                    // column tiles per workgroup (128 columns)
+            int64_t bt = 4 ;                    // column tiles per workgroup: 128 columns (64 and 256 measured slower)
             while ((int64_t) frefs.size ( ) * ((ntiles - t0 + bt - 1) / bt) > 16384 && bt < 64) bt *= 2 ;
             const int64_t cb = t0 * QR_PANEL_W ;
             const int64_t ce = fn ;
@@ -325,7 +332,7 @@ static int32_t plan_front
                     st.t.type = QR_TASK_APPLY ;
                     st.t.tier = tier_of (fr.K) ;
                     QrPanelTask &pt = st.t.u.panel ;
-                    pt.F = F ; pt.VT = NULL ; pt.ld = (int32_t) fn ; pt.col0 = (int32_t) c0 ; pt.w = (int32_t) w ;
+                    pt.F = F ; pt.VT = NULL ; pt.ld = (int32_t) ld ; pt.col0 = (int32_t) c0 ; pt.w = (int32_t) w ;
                     pt.K = fr.K ; pt.nseg = fr.nseg ; pt.c_begin = (int32_t) cb ; pt.c_end = (int32_t) ce ;
                     pt.cb_cols = (int32_t) (bt * QR_PANEL_W) ;
                     for (int s = 0 ; s < fr.nseg ; s++) { pt.seg_row [s] = fr.segs [s].row ; pt.seg_n [s] = fr.segs [s].n ; }
@@ -351,7 +358,7 @@ extern "C" int64_t gpuqr_front_flops (int64_t fm, int64_t fn, const int64_t *Sta
     try
     {
         Plan plan ;
-        plan_front (plan, NULL, fm, fn, Stair, 1, false) ;
+        plan_front (plan, NULL, fm, fn, fn, Stair, 1, false) ;
         return plan.flops ;
     }
     catch (std::bad_alloc &) { return -1 ; }
@@ -459,6 +466,23 @@ extern "C" void gpuqr_finalize (void)
     if (cur >= 0) (void) hipSetDevice (cur) ;
 }
 
+// Row pitch of a device-resident front: fn, or ldn when the caller padded the rows.
+static inline int64_t front_pitch (const gpuqr_front &fr)
+{
+    return (!fr.is_col_major && fr.ldn > fr.fn) ? fr.ldn : fr.fn ;
+}
+
+// The first nrows rows of a device front to packed host rows of fn entries.
+static hipError_t pull_rows (const gpuqr_front &fr, int64_t nrows, hipStream_t stream)
+{
+    const int64_t ld = front_pitch (fr) ;
+    if (nrows <= 0 || fr.fn <= 0) return hipSuccess ;
+    if (ld == fr.fn)
+        return hipMemcpyAsync (fr.cpuR, fr.gpuF, (size_t) (nrows * fr.fn) * sizeof (double), hipMemcpyDeviceToHost, stream) ;
+    return hipMemcpy2DAsync (fr.cpuR, (size_t) fr.fn * sizeof (double), fr.gpuF, (size_t) ld * sizeof (double),
+        (size_t) fr.fn * sizeof (double), (size_t) nrows, hipMemcpyDeviceToHost, stream) ;
+}
+
 static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
 {
     int code = GPUQR_SUCCESS ;
@@ -486,6 +510,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
             if (fr.pids < -1 || fr.pids >= nf || fr.pids == f) return GPUQR_GPUERROR ;
             if (fr.fm < 0 || fr.fn < 0 || fr.fm > INT32_MAX || fr.fn > INT32_MAX) return GPUQR_GPUERROR ;
             if (fr.fm > 0 && fr.fn > 0 && fr.gpuF == NULL) return GPUQR_GPUERROR ;
+            if (front_pitch (fr) > INT32_MAX) return GPUQR_GPUERROR ;
             if (fr.is_sparse && fr.pids >= 0 && fr.cm > 0 && fr.cn > 0)
             {
                 if (!fr.gpuRimap || !fr.gpuRjmap || !fr.gpuC) return GPUQR_GPUERROR ;
@@ -535,6 +560,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                         st.t.u.sasm.F = fr.gpuF ; st.t.u.sasm.S = fr.gpuS ;
                         st.t.u.sasm.pstart = ps ;
                         st.t.u.sasm.pend = std::min (ps + (int64_t) QR_SASM_CHUNK, fr.Scount) ;
+                        st.t.u.sasm.fn = (int32_t) fr.fn ; st.t.u.sasm.ld = (int32_t) front_pitch (fr) ;
                         st.round = 0 ; st.vt = -1 ; st.nblk = 1 ;
                         st.flops = 0 ;
                         st.bytes = 24.0 * (double) (st.t.u.sasm.pend - st.t.u.sasm.pstart) ;   // 16 read + 8 written
@@ -546,7 +572,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                 // panel round of one coinciding with the panel rounds of the others; shifting their
                 // starts over a few rounds lets one front's updates overlap another's panels
                 if (child_pack_round [f] == 0 && g_stagger > 1) start += (int32_t) ((nleaf++) % g_stagger) ;
-                done = plan_front (plan, fr.gpuF, fr.fm, fr.fn, fr.Stair, start, true) ;
+                done = plan_front (plan, fr.gpuF, fr.fm, fr.fn, front_pitch (fr), fr.Stair, start, true) ;
                 if (done < start - 1) done = start - 1 ;
             }
             done_round [f] = done ;
@@ -558,7 +584,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
             if (fr.is_sparse && fr.pids >= 0 && fr.cm > 0 && fr.cn > 0)
             {
                 const int32_t round = done + 1 ;
-                const int32_t cld = fr.push_only ? fr.cn : (int32_t) fr.fn ;
+                const int32_t cld = fr.push_only ? fr.cn : (int32_t) front_pitch (fr) ;
                 for (int32_t ci = 0 ; ci < fr.cm ; ci += QR_PACK_TILE)
                 {
                     for (int32_t cj = (ci / QR_PACK_TILE) * QR_PACK_TILE ; cj < fr.cn ; cj += QR_PACK_TILE)
@@ -568,7 +594,8 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                         QrPackAssembleTask &pk = st.t.u.pack ;
                         pk.C = fr.gpuC ; pk.P = fronts [fr.pids].gpuF ;
                         pk.Rjmap = fr.gpuRjmap ; pk.Rimap = fr.gpuRimap ;
-                        pk.cld = cld ; pk.pn = fr.pn ;
+                        pk.cld = cld ;
+                        pk.pn = (int32_t) std::max<int64_t> (fr.pn, front_pitch (fronts [fr.pids])) ;
                         pk.cistart = ci ; pk.ciend = std::min (ci + QR_PACK_TILE, fr.cm) ;
                         pk.cjstart = cj ; pk.cjend = std::min (cj + QR_PACK_TILE, fr.cn) ;
                         st.round = round ; st.vt = -1 ; st.nblk = 1 ;
@@ -613,6 +640,25 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                 const int64_t b = (int64_t) st.round * QR_NKERNELS + qr_task_kernel_id (st.t.type, st.t.tier) ;
                 bflops [b] += st.flops ; bbytes [b] += st.bytes ;
             }
+        }
+
+        if (getenv ("GPUQR_PLAN_STATS"))
+        {
+            // diagnostic: how full the 256-row apply workgroups are
+            double wg = 0, wgK [4] = {0,0,0,0}, wgodd = 0, wgmis = 0, wgseg = 0, colsum = 0 ;
+            for (int64_t i = 0 ; i < ntasks ; i++)
+            {
+                const SchedTask &st = plan.tasks [i] ;
+                if (st.t.type != QR_TASK_APPLY || st.t.tier != 3) continue ;
+                const QrPanelTask &pt = st.t.u.panel ;
+                wg += st.nblk ; wgK [(pt.K - 129) / 32] += st.nblk ;
+                if (pt.ld & 1) wgodd += st.nblk ; else if (((uintptr_t) pt.F >> 3) & 1) wgmis += st.nblk ;
+                if (pt.nseg > 1) wgseg += st.nblk ;
+                colsum += pt.c_end - pt.c_begin ;
+            }
+            fprintf (stderr, "plan: apply<16> workgroups %.0f; K 129-160 %.1f%% 161-192 %.1f%% 193-224 %.1f%% 225-256 %.1f%%; odd ld %.1f%%, "
+                "even ld odd base %.1f%%; gathered %.1f%%; mean columns per workgroup %.1f; rounds %d\n", wg, 100*wgK[0]/wg, 100*wgK[1]/wg,
+                100*wgK[2]/wg, 100*wgK[3]/wg, 100*wgodd/wg, 100*wgmis/wg, 100*wgseg/wg, colsum/wg, nrounds) ;
         }
 
         dc = device_cache ( ) ;
@@ -720,11 +766,10 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
             {
                 gpuqr_front &fr = fronts [f] ;
                 if (fr.cpuR == NULL || (fr.is_sparse && fr.push_only)) continue ;
-                int64_t nvals = fr.rank * fr.fn ;
-                if (fr.is_sparse && fr.is_staged) nvals += (int64_t) fr.cm * fr.fn ;
-                if (nvals > fr.fm * fr.fn) nvals = fr.fm * fr.fn ;
-                if (nvals > 0)
-                    HIP_TRY (hipMemcpyAsync (fr.cpuR, fr.gpuF, (size_t) nvals * sizeof (double), hipMemcpyDeviceToHost, sCompute)) ;
+                int64_t nrows = fr.rank ;
+                if (fr.is_sparse && fr.is_staged) nrows += fr.cm ;
+                if (nrows > fr.fm) nrows = fr.fm ;
+                HIP_TRY (pull_rows (fr, nrows, sCompute)) ;
             }
             HIP_TRY (hipStreamSynchronize (sCompute)) ;
             HIP_TRY (hipEventElapsedTime (&ms, evStart, evStop)) ;
@@ -852,11 +897,10 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                     while (pi < pull_order.size ( ) && std::min (done_round [pull_order [pi]], nrounds - 1) <= r)
                     {
                         gpuqr_front &fr = fronts [pull_order [pi++]] ;
-                        int64_t nvals = fr.rank * fr.fn ;
-                        if (fr.is_sparse && fr.is_staged) nvals += (int64_t) fr.cm * fr.fn ;
-                        if (nvals > fr.fm * fr.fn) nvals = fr.fm * fr.fn ;
-                        if (nvals > 0)
-                            HIP_TRY (hipMemcpyAsync (fr.cpuR, fr.gpuF, (size_t) nvals * sizeof (double), hipMemcpyDeviceToHost, sCopy)) ;
+                        int64_t nrows = fr.rank ;
+                        if (fr.is_sparse && fr.is_staged) nrows += fr.cm ;
+                        if (nrows > fr.fm) nrows = fr.fm ;
+                        HIP_TRY (pull_rows (fr, nrows, sCopy)) ;
                     }
                 }
             }
@@ -933,7 +977,7 @@ extern "C" int gpuqr_factor_dense
     {
         gpuqr_front &u = userFronts [f] ;
         if (u.fm < 0 || u.fn < 0 || (u.fm > 0 && u.fn > 0 && (!u.F || !u.cpuR))) { code = GPUQR_GPUERROR ; goto cleanup ; }
-        FSize += (size_t) u.fm * u.fn ;
+        FSize += (size_t) u.fm * (size_t) (u.fn + (u.fn & 1)) ;
         RSize += (size_t) std::min (u.fm, u.fn) * u.fn ;
     }
     // pinned staging copies: the H2D/D2H transfers then run asynchronously
@@ -954,19 +998,27 @@ extern "C" int gpuqr_factor_dense
             fr.fids = f ; fr.pids = -1 ; fr.fidg = u.fidg ; fr.pidg = u.pidg ;
             fr.fm = m ; fr.fn = n ; fr.fp = u.fp ; fr.rank = std::min (m, n) ;
             fr.is_sparse = 0 ;
+            // rows of the device copy are padded to an even length: with the 16-byte aligned
+            // base every row then starts on a 16-byte boundary, which the update kernel's
+            // two-column accesses want
+            const int64_t np = n + (n & 1) ;
+            fr.is_col_major = 0 ; fr.ldn = np ;
             double *F = hF + FOff ;
             fr.F = F ; fr.gpuF = dF + FOff ; fr.cpuR = hR + ROff ;
             for (int64_t i = 0 ; i < m ; i++)
+            {
                 for (int64_t j = 0 ; j < n ; j++)
-                    F [i*n + j] = u.is_col_major ? u.F [j*ldn + i] : u.F [i*ldn + j] ;
+                    F [i*np + j] = u.is_col_major ? u.F [j*ldn + i] : u.F [i*ldn + j] ;
+                if (np > n) F [i*np + n] = 0 ;
+            }
             fr.Stair = u.Stair ;
             if (fr.Stair == NULL && m > 0 && n > 0)
             {
-                ownStair [f] = gpuqr_find_staircase (F, m, n) ;
+                ownStair [f] = find_staircase_ld (F, m, n, np) ;
                 if (!ownStair [f]) { code = GPUQR_OUTOFMEMORY ; goto cleanup ; }
                 fr.Stair = ownStair [f] ;
             }
-            FOff += (size_t) m * n ;
+            FOff += (size_t) m * np ;
             ROff += (size_t) fr.rank * n ;
         }
     }

@@ -553,9 +553,19 @@ __device__ void sassemble (const QrSAssembleTask &t)
     typedef __attribute__((address_space(1))) const long long gcll ;
     gcll *S = (gcll *) t.S ;
     gdouble *F = (gdouble *) t.F ;
-    for (int64_t p = t.pstart + threadIdx.x ; p < t.pend ; p += QR_THREADS)
+    if (t.ld == t.fn)
     {
-        F [S [2*p]] = __longlong_as_double (S [2*p + 1]) ;
+        for (int64_t p = t.pstart + threadIdx.x ; p < t.pend ; p += QR_THREADS)
+            F [S [2*p]] = __longlong_as_double (S [2*p + 1]) ;
+    }
+    else
+    {
+        // rows of the front are padded to ld entries: split the packed index
+        for (int64_t p = t.pstart + threadIdx.x ; p < t.pend ; p += QR_THREADS)
+        {
+            const long long k = S [2*p], i = k / t.fn ;
+            F [i * t.ld + (k - i * t.fn)] = __longlong_as_double (S [2*p + 1]) ;
+        }
     }
 }
 
@@ -583,6 +593,66 @@ __device__ void packassemble (const QrPackAssembleTask &t, char *smem)
             if (cj >= ci) Prow [shRjmap [cjl]] = Crow [cj] ;
         }
     }
+}
+
+// -----------------------------------------------------------------------------
+// R hand-off
+// -----------------------------------------------------------------------------
+//
+// Row-major R rows -> SPQR's column-packed stack layout (the job of the host loop at
+// spqrgpu_kernel.cpp:417-439), on the device so that only the packed entries cross PCIe.
+// One workgroup per (front, 32-row tile): it walks the 32-column tiles at and right of the
+// diagonal, reads each with lanes along the row (contiguous in the front) and writes it with
+// lanes along the column (contiguous in the packed block), through a padded LDS tile.
+// tile_prefix [f] = number of row tiles of fronts before f.
+
+__global__ void __launch_bounds__ (QR_THREADS) k_pack_r (const QrPackRTask *tasks, const long long *tile_prefix, int nfronts)
+{
+    __shared__ double tile [32][33] ;
+    // front of this workgroup: last f with tile_prefix [f] <= blockIdx.x
+    int lo = 0, hi = nfronts - 1 ;
+    while (lo < hi)
+    {
+        const int mid = (lo + hi + 1) >> 1 ;
+        if (tile_prefix [mid] <= (long long) blockIdx.x) lo = mid ; else hi = mid - 1 ;
+    }
+    const QrPackRTask t = tasks [lo] ;
+    const int i0 = 32 * (int) ((long long) blockIdx.x - tile_prefix [lo]) ;
+    gcdouble *F = (gcdouble *) t.F ;
+    gdouble *out = (gdouble *) t.out ;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5 ;
+    const long long frank = t.frank, tri = frank * (frank + 1) / 2 ;
+    for (int j0 = i0 ; j0 < t.fn ; j0 += 32)
+    {
+        #pragma unroll
+        for (int k = 0 ; k < 4 ; k++)
+        {
+            const int i = i0 + ty + 8*k, j = j0 + tx ;
+            tile [ty + 8*k][tx] = (i < t.frank && j < t.fn) ? F [(size_t) i * t.ld + j] : 0.0 ;
+        }
+        __syncthreads ( ) ;
+        #pragma unroll
+        for (int k = 0 ; k < 4 ; k++)
+        {
+            const int i = i0 + tx ;
+            const long long j = j0 + ty + 8*k ;
+            if (i < t.frank && j < t.fn && j >= i)
+            {
+                const long long col = (j < frank) ? (j * (j + 1) / 2) : (tri + (j - frank) * frank) ;
+                out [col + i] = tile [tx][ty + 8*k] ;
+            }
+        }
+        __syncthreads ( ) ;
+    }
+}
+
+extern "C" hipError_t qr_launch_pack_r (const QrPackRTask *d_tasks, const long long *d_tile_prefix, int nfronts,
+    long long ntiles, hipStream_t stream)
+{
+    if (nfronts <= 0 || ntiles <= 0) return hipSuccess ;
+    if (ntiles > 0x7fffffffLL) return hipErrorInvalidValue ;
+    hipLaunchKernelGGL (k_pack_r, dim3 ((unsigned) ntiles), dim3 (QR_THREADS), 0, stream, d_tasks, d_tile_prefix, nfronts) ;
+    return hipGetLastError ( ) ;
 }
 
 // -----------------------------------------------------------------------------

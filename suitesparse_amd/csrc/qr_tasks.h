@@ -54,6 +54,7 @@ struct QrSAssembleTask
     double       *F;            // destination front
     const void   *S;            // packed (int64 findex, double value) pairs
     int64_t       pstart, pend; // slice of S
+    int32_t       fn, ld;       // findex = i*fn + j addresses F[i*ld + j]; no conversion when ld == fn
 };
 
 struct QrPackAssembleTask
@@ -83,6 +84,15 @@ struct QrQueueRef
     int32_t wait_ctr;
     int32_t need;
     int32_t signal_ctr;
+};
+
+// R hand-off: the first frank rows of a reduced front (row-major, row pitch ld) go to a
+// column-packed upper trapezoid: column j holds min(j+1, frank) entries, columns one after another.
+struct QrPackRTask
+{
+    const double *F;            // reduced front
+    double       *out;          // its block of the packed stack
+    int32_t       ld, fn, frank, pad;
 };
 
 #define QR_QUEUE_HEAD   0       // counters[0]: next ticket

@@ -206,21 +206,6 @@ template <class Body> static void parallel_for (Long n, Body body)
     for (size_t t = 0 ; t < pool.size ( ) ; t++) pool [t].join ( ) ;
 }
 
-// The first frank rows of a reduced front (row-major, unpacked) -> SPQR's column-packed upper
-// trapezoid (spqrgpu_kernel.cpp:417-439), walking the source row by row so that the reads
-// from the pinned pull buffer are contiguous.  Column j holds min(j+1, frank) entries.
-static void pack_r_block (const double *cpuF, Long fn, Long frank, double *out)
-{
-    const Long tri = frank * (frank + 1) / 2 ;
-    for (Long i = 0 ; i < frank ; i++)
-    {
-        const double *row = cpuF + fn * i ;
-        for (Long j = i ; j < frank ; j++) out [j * (j + 1) / 2 + i] = row [j] ;
-        double *rect = out + tri + i ;
-        for (Long j = frank ; j < fn ; j++) rect [(j - frank) * frank] = row [j] ;
-    }
-}
-
 static inline Long r_block_size (Long fn, Long frank)
 {
     return frank * (frank + 1) / 2 + frank * (fn - frank) ;
@@ -236,26 +221,61 @@ static double now_ms (void)
 // GPUQR_VERBOSE=1 prints where the host time of the numeric driver goes
 #define TICK(label) do { if (verbose) { double t_ = now_ms ( ) ; fprintf (stderr, "  [spqrgpu] %-28s %9.2f ms\n", label, t_ - tlast) ; tlast = t_ ; } } while (0)
 
+struct QrPackRTask ;
+extern "C" hipError_t qr_launch_pack_r (const QrPackRTask *d_tasks, const long long *d_tile_prefix, int nfronts,
+    long long ntiles, hipStream_t stream) ;
+struct PackRTask { const double *F ; double *out ; int32_t ld, fn, frank, pad ; } ;     // = QrPackRTask (qr_tasks.h)
+
 extern "C" void spqr_amd_numeric_free (spqr_amd_numeric *num)
 {
     if (!num) return ;
-    free (num->Rstack) ; free (num->Rblock) ; free (num->Rdead) ; free (num->Cstack) ; free (num->Cblock) ;
+    if (num->Rstack) (void) hipHostFree (num->Rstack) ;      // pinned: the packed R arrives by DMA
+    free (num->Rblock) ; free (num->Rdead) ; free (num->Cstack) ; free (num->Cblock) ;
     free (num) ;
 }
 
-// One call = the whole numeric factorization of A = Q R on the device, stage
-// by stage.  Mirrors spqrgpu_kernel.cpp:63-782: build S and the maps, then per
-// stage zero the front arena, ship S, describe the fronts (plus push-only
-// fronts for contribution blocks that waited in host "limbo"), run the
-// engine, pack R column-wise onto the stack and park the C blocks of fronts
-// whose parent lives in a later stage.
-extern "C" int spqrgpu_amd_factorize
+// Grow-only device / pinned buffer
+struct Buf
+{
+    void *p = NULL ; size_t cap = 0 ; bool pinned = false ;
+    hipError_t ensure (size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess ;
+        release ( ) ;
+        bytes = std::max (bytes, (size_t) 256) ;
+        hipError_t e = pinned ? hipHostMalloc (&p, bytes, hipHostMallocDefault) : hipMalloc (&p, bytes) ;
+        if (e != hipSuccess) { p = NULL ; return e ; }
+        cap = bytes ;
+        return hipSuccess ;
+    }
+    void release ( ) { if (p) { if (pinned) (void) hipHostFree (p) ; else (void) hipFree (p) ; } p = NULL ; cap = 0 ; }
+    ~Buf ( ) { release ( ) ; }
+} ;
+
+// The numeric factorization of a set of fronts, group by group.  Mirrors
+// spqrgpu_kernel.cpp:63-782: build S and the maps, then per group (a stage of
+// the staging, or one process's share of the tree) zero the front arena, ship
+// S, describe the fronts (plus push-only fronts for contribution blocks that
+// come from outside the group), run the engine, and hand R back.
+//
+// Device layout of a group, chosen here (the staging's FOffsets price the memory
+// but do not bind the placement): fronts one after another in postorder, each
+// with its rows padded to an even length so that every row starts on a 16-byte
+// boundary, each followed by the compact contribution blocks of its children
+// from outside the group.  R never visits the host unpacked: a kernel writes
+// the column-packed upper trapezoids of all fronts of the group into one
+// device block laid out like the final stack, and a single DMA moves that block
+// into the pinned Rstack.
+//
+// mine == NULL: all fronts, groups = stages, blocks leaving a stage wait in host
+// limbo.  mine != NULL: one group of the fronts with mine[f] != 0, blocks
+// arriving from limbo_in, blocks leaving through num->Cstack.
+static int factorize_impl
 (
     const spqr_amd_symbolic *S, const int64_t *Ap, const int64_t *Ai, const double *Ax,
-    spqr_amd_numeric **num_out
+    const char *mine, const double *const *limbo_in, spqr_amd_numeric **num_out
 )
 {
-    if (!S || !Ap || !Ax || !num_out) return 3 ;
     *num_out = NULL ;
     int code = 0 ;
     const bool verbose = getenv ("GPUQR_VERBOSE") != NULL ;
@@ -268,20 +288,41 @@ extern "C" int spqrgpu_amd_factorize
 
     spqr_amd_numeric *num = (spqr_amd_numeric *) calloc (1, sizeof (spqr_amd_numeric)) ;
     if (!num) return 1 ;
-    double *dF = NULL ; gpuqr_sentry *dS = NULL ; int32_t *dRimap = NULL, *dRjmap = NULL ;
-    double *hR [2] = {NULL, NULL} ; gpuqr_sentry *hS = NULL ;
-    gpuqr_front *fronts = NULL ;
+    Buf dF, dS, dR, dRimap, dRjmap, dTasks, dPrefix, hS, hStage ;
+    hS.pinned = true ; hStage.pinned = true ;
+    std::vector<gpuqr_front> fronts ;
     std::vector<double *> limbo ;
 
     try
     {
-        if (S->numStages <= 0 && nf > 0) { code = 2 ; goto done ; }
+        if (!mine && S->numStages <= 0 && nf > 0) { code = 2 ; goto done ; }
+
+        // ---- what this call factorizes, and the size of its R ------------------------------
+        auto S_count = [&] (Long f) { return std::max ((Long) 0, Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]]) ; } ;
+        auto is_mine = [&] (Long f) { return mine == NULL || mine [f] != 0 ; } ;
+        Long rtotal = 0, ctotal = 0 ;
+        for (Long f = 0 ; f < nf ; f++)
+        {
+            if (!is_mine (f)) continue ;
+            const Long fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
+            rtotal += r_block_size (fn, std::min (Fm [f], fp)) ;
+            if (mine && Parent [f] < nf && !mine [Parent [f]]) ctotal += Cm [f] * (fn - fp) ;
+        }
         num->nf = nf ;
-        num->rsize = S->rnz ;
-        num->Rstack = (double *) malloc (std::max ((Long) 1, S->rnz) * sizeof (double)) ;
-        num->Rblock = (Long *) calloc (std::max ((Long) 1, nf), sizeof (Long)) ;
-        num->Rdead = (char *) calloc (std::max ((Long) 1, n), 1) ;
-        if (!num->Rstack || !num->Rblock || !num->Rdead) { code = 1 ; goto done ; }
+        num->rsize = rtotal ;
+        if (hipHostMalloc ((void **) &num->Rstack, (size_t) std::max ((Long) 1, rtotal) * sizeof (double), hipHostMallocDefault) != hipSuccess)
+            { num->Rstack = NULL ; code = 1 ; goto done ; }
+        num->Rblock = (Long *) malloc ((size_t) std::max ((Long) 1, nf) * sizeof (Long)) ;
+        num->Rdead = (char *) calloc ((size_t) std::max ((Long) 1, n), 1) ;
+        if (!num->Rblock || !num->Rdead) { code = 1 ; goto done ; }
+        for (Long f = 0 ; f < nf ; f++) num->Rblock [f] = -1 ;
+        if (mine)
+        {
+            num->Cstack = (double *) calloc ((size_t) std::max ((Long) 1, ctotal), sizeof (double)) ;
+            num->Cblock = (Long *) malloc ((size_t) std::max ((Long) 1, nf) * sizeof (Long)) ;
+            if (!num->Cstack || !num->Cblock) { code = 1 ; goto done ; }
+            for (Long f = 0 ; f < nf ; f++) num->Cblock [f] = -1 ;
+        }
 
         // ---- Sx: values of S in row order (spqr_stranspose2) ------------------------------
         std::vector<double> Sx ((size_t) S->anz) ;
@@ -293,125 +334,158 @@ extern "C" int spqrgpu_amd_factorize
                 for (Long p = Ap [col] ; p < Ap [col+1] ; p++) Sx [w [S->PLinv [Ai [p]]]++] = Ax [p] ;
             }
         }
-
         TICK ("alloc + Sx") ;
+
         // ---- maps and packed S for the whole problem ---------------------------------------
         const Long RimapSize = std::max ((Long) 1, S->RimapSize), RjmapSize = std::max ((Long) 1, S->RjmapSize) ;
         std::vector<Long> Stair ((size_t) std::max ((Long) 1, Rp [nf])), Fmap ((size_t) std::max ((Long) 1, n)) ;
         std::vector<int32_t> Rimap ((size_t) RimapSize), Rjmap ((size_t) RjmapSize) ;
-        if (hipHostMalloc ((void **) &hS, std::max ((Long) 1, S->anz) * sizeof (gpuqr_sentry), hipHostMallocDefault) != hipSuccess) { hS = NULL ; code = 1 ; goto done ; }
+        if (hS.ensure ((size_t) std::max ((Long) 1, S->anz) * sizeof (gpuqr_sentry)) != hipSuccess) { code = 1 ; goto done ; }
+        gpuqr_sentry *allS = (gpuqr_sentry *) hS.p ;
         spqrgpu_amd_build_assembly_maps (nf, n, Fmap.data ( ), Post, Super, Rp, S->Rj.data ( ), Sleft, Sp,
             S->Sj.data ( ), Sx.data ( ), Fm, Cm, Childp, Child, Stair.data ( ), Rjmap.data ( ),
-            S->RjmapOffsets.data ( ), Rimap.data ( ), S->RimapOffsets.data ( ), hS) ;
-        if (hipMalloc ((void **) &dRimap, RimapSize * sizeof (int32_t)) != hipSuccess) { dRimap = NULL ; code = 1 ; goto done ; }
-        if (hipMalloc ((void **) &dRjmap, RjmapSize * sizeof (int32_t)) != hipSuccess) { dRjmap = NULL ; code = 1 ; goto done ; }
-        HIPCHK (hipMemcpy (dRimap, Rimap.data ( ), RimapSize * sizeof (int32_t), hipMemcpyHostToDevice)) ;
-        HIPCHK (hipMemcpy (dRjmap, Rjmap.data ( ), RjmapSize * sizeof (int32_t), hipMemcpyHostToDevice)) ;
-
-        TICK ("assembly maps + upload") ;
-        // ---- workspaces sized for the largest stage -----------------------------------------
-        size_t maxF = 1, maxR = 1, maxS = 1 ; Long maxfronts = 1 ;
-        for (Long st = 0 ; st < S->numStages ; st++)
+            S->RjmapOffsets.data ( ), Rimap.data ( ), S->RimapOffsets.data ( ), allS) ;
+        // packed S is laid out front after front in postorder
+        std::vector<Long> SGlob ((size_t) nf + 1, 0) ;
         {
-            maxF = std::max (maxF, (size_t) S->FSize [st]) ;
-            maxR = std::max (maxR, (size_t) S->RSize [st]) ;
-            maxS = std::max (maxS, (size_t) S->SSize [st]) ;
-            maxfronts = std::max (maxfronts, Stagingp [st+1] - Stagingp [st]
-                + spqrgpu_amd_numfronts_in_stage (st, Stagingp, StageMap, Post, Child, Childp)) ;
+            Long sacc = 0 ;
+            for (Long k = 0 ; k < nf ; k++) { SGlob [Post [k]] = sacc ; sacc += S_count (Post [k]) ; }
         }
-        if (hipMalloc ((void **) &dF, maxF * sizeof (double)) != hipSuccess) { dF = NULL ; code = 1 ; goto done ; }
-        if (hipMalloc ((void **) &dS, maxS * sizeof (gpuqr_sentry)) != hipSuccess) { dS = NULL ; code = 1 ; goto done ; }
-        if (hipHostMalloc ((void **) &hR [0], maxR * sizeof (double), hipHostMallocDefault) != hipSuccess) { hR [0] = NULL ; code = 1 ; goto done ; }
-        fronts = (gpuqr_front *) malloc ((size_t) maxfronts * sizeof (gpuqr_front)) ;
-        if (!fronts) { code = 1 ; goto done ; }
+        if (dRimap.ensure ((size_t) RimapSize * sizeof (int32_t)) != hipSuccess) { code = 1 ; goto done ; }
+        if (dRjmap.ensure ((size_t) RjmapSize * sizeof (int32_t)) != hipSuccess) { code = 1 ; goto done ; }
+        HIPCHK (hipMemcpy (dRimap.p, Rimap.data ( ), (size_t) RimapSize * sizeof (int32_t), hipMemcpyHostToDevice)) ;
+        HIPCHK (hipMemcpy (dRjmap.p, Rjmap.data ( ), (size_t) RjmapSize * sizeof (int32_t), hipMemcpyHostToDevice)) ;
+        TICK ("assembly maps + upload") ;
+
         limbo.assign ((size_t) std::max ((Long) 1, nf), (double *) NULL) ;
+        std::vector<Long> rel ((size_t) std::max ((Long) 1, nf), -1), pitch ((size_t) std::max ((Long) 1, nf), 0) ;
+        for (Long f = 0 ; f < nf ; f++) { const Long fn = Rp [f+1] - Rp [f] ; pitch [f] = fn + (fn & 1) ; }
 
-        std::vector<Long> InvPost ((size_t) nf + 1) ;
-        for (Long k = 0 ; k < nf ; k++) InvPost [Post [k]] = k ;
-        InvPost [nf] = nf ;
-
-        TICK ("workspace allocation") ;
-        Long SOffset = 0 ;
-        Long rhead = 0 ;            // next free slot of Rstack
-        for (Long stage = 0 ; stage < S->numStages ; stage++)
+        const Long ngroups = mine ? 1 : S->numStages ;
+        Long rhead = 0, chead = 0 ;
+        std::vector<Long> list, FOff, SOff, ROff ;
+        std::vector<PackRTask> ptasks ;
+        std::vector<long long> prefix ;
+        for (Long g = 0 ; g < ngroups ; g++)
         {
-            const Long sStart = Stagingp [stage], sEnd = Stagingp [stage+1] ;
-            const Long numFronts = sEnd - sStart ;
-            Long next_child = numFronts ;
-            HIPCHK (hipMemset (dF, 0, std::max ((size_t) 1, (size_t) S->FSize [stage]) * sizeof (double))) ;
-            if (S->SSize [stage] > 0)
-                HIPCHK (hipMemcpy (dS, hS + SOffset, (size_t) S->SSize [stage] * sizeof (gpuqr_sentry), hipMemcpyHostToDevice)) ;
-            SOffset += S->SSize [stage] ;
+            // ---- fronts of the group, in postorder -----------------------------------------
+            list.clear ( ) ;
+            if (mine) { for (Long k = 0 ; k < nf ; k++) if (mine [Post [k]]) list.push_back (Post [k]) ; }
+            else for (Long p = Stagingp [g] ; p < Stagingp [g+1] ; p++) list.push_back (Post [p]) ;
+            const Long numFronts = (Long) list.size ( ) ;
+            if (numFronts == 0) { if (!mine) num->numStagesRun++ ; continue ; }
+            auto in_group = [&] (Long f) { return f < nf && (mine ? (mine [f] != 0) : (StageMap [f] == g)) ; } ;
 
-            for (Long p = sStart ; p < sEnd ; p++)
+            // ---- layout ---------------------------------------------------------------------
+            FOff.assign ((size_t) numFronts, 0) ; SOff.assign ((size_t) numFronts, 0) ; ROff.assign ((size_t) numFronts, 0) ;
+            Long fsum = 0, ssum = 0, rsum = 0, nlimbo = 0 ;
+            for (Long k = 0 ; k < numFronts ; k++)
             {
-                const Long f = Post [p] ;
-                const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
-                const Long frank = std::min (fm, fp) ;
-                const Long rel = p - sStart ;
-                const Long pid = Parent [f] ;
-                Long prel = -1 ;
-                if (pid < nf && StageMap [pid] == stage) prel = InvPost [pid] - sStart ;
-
-                gpuqr_front &fr = fronts [rel] ;
-                memset (&fr, 0, sizeof (fr)) ;
-                fr.fids = rel ; fr.pids = prel ; fr.fidg = f ; fr.pidg = pid ;
-                fr.fm = fm ; fr.fn = fn ; fr.fp = fp ; fr.rank = frank ;
-                fr.ldn = fn ;
-                fr.Stair = Stair.data ( ) + Rp [f] ;
-                fr.gpuF = dF + S->FOffsets [f] ;
-                fr.cpuR = hR [0] + S->ROffsets [f] ;
-                fr.is_sparse = 1 ;
-                fr.nc = (int32_t) (Childp [f+1] - Childp [f]) ;
-                fr.Scount = std::max ((Long) 0, Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]]) ;
-                fr.gpuS = dS + S->SOffsets [f] ;
-                fr.cn = (int32_t) (fn - fp) ;
-                fr.cm = (int32_t) Cm [f] ;
-                if (prel != -1)
-                {
-                    fr.pn = (int32_t) (Rp [pid+1] - Rp [pid]) ;
-                    fr.gpuRjmap = dRjmap + S->RjmapOffsets [f] ;
-                    fr.gpuRimap = dRimap + S->RimapOffsets [f] ;
-                    fr.gpuC = fr.gpuF + frank * fn + fp ;
-                }
-                else if (pid < nf)
-                {
-                    fr.is_staged = 1 ;      // parent is factorized in a later stage
-                }
-
-                // children factorized in earlier stages: their C blocks come back from limbo
-                // and sit right behind the front in the arena (the staging reserved the room)
-                Long child_off = S->FOffsets [f] + fm * fn ;
+                const Long f = list [k] ;
+                rel [f] = k ;
+                const Long fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
+                FOff [k] = fsum ; SOff [k] = ssum ; ROff [k] = rsum ;
+                fsum += Fm [f] * pitch [f] ;
                 for (Long cp = Childp [f] ; cp < Childp [f+1] ; cp++)
                 {
                     const Long c = Child [cp] ;
-                    if (StageMap [c] == stage) continue ;
+                    if (in_group (c)) continue ;
+                    nlimbo++ ;
+                    fsum += Cm [c] * ((Rp [c+1] - Rp [c]) - (Super [c+1] - Super [c])) ;
+                    fsum += (fsum & 1) ;
+                }
+                ssum += S_count (f) ;
+                rsum += r_block_size (fn, std::min (Fm [f], fp)) ;
+            }
+            if (dF.ensure ((size_t) std::max ((Long) 1, fsum) * sizeof (double)) != hipSuccess) { code = 1 ; goto done ; }
+            if (dS.ensure ((size_t) std::max ((Long) 1, ssum) * sizeof (gpuqr_sentry)) != hipSuccess) { code = 1 ; goto done ; }
+            if (dR.ensure ((size_t) std::max ((Long) 1, rsum) * sizeof (double)) != hipSuccess) { code = 1 ; goto done ; }
+            double *F0 = (double *) dF.p ;
+            gpuqr_sentry *S0 = (gpuqr_sentry *) dS.p ;
+            fronts.assign ((size_t) (numFronts + nlimbo), gpuqr_front ( )) ;
+            TICK ("workspace allocation") ;
+
+            HIPCHK (hipMemsetAsync (F0, 0, (size_t) std::max ((Long) 1, fsum) * sizeof (double), 0)) ;
+            // S entries of the group: runs of fronts that are neighbours in postorder go in one copy
+            for (Long k = 0 ; k < numFronts ; )
+            {
+                Long k2 = k, cnt = 0 ;
+                while (k2 < numFronts && SGlob [list [k2]] == SGlob [list [k]] + cnt) { cnt += S_count (list [k2]) ; k2++ ; }
+                if (cnt > 0)
+                    HIPCHK (hipMemcpyAsync (S0 + SOff [k], allS + SGlob [list [k]], (size_t) cnt * sizeof (gpuqr_sentry), hipMemcpyHostToDevice, 0)) ;
+                k = k2 ;
+            }
+
+            Long next_child = numFronts ;
+            for (Long k = 0 ; k < numFronts ; k++)
+            {
+                const Long f = list [k] ;
+                const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
+                const Long frank = std::min (fm, fp) ;
+                const Long pid = Parent [f] ;
+                const bool parent_here = in_group (pid) ;
+
+                gpuqr_front &fr = fronts [k] ;
+                memset (&fr, 0, sizeof (fr)) ;
+                fr.fids = k ; fr.pids = parent_here ? rel [pid] : -1 ; fr.fidg = f ; fr.pidg = pid ;
+                fr.fm = fm ; fr.fn = fn ; fr.fp = fp ; fr.rank = frank ;
+                fr.ldn = pitch [f] ;
+                fr.Stair = Stair.data ( ) + Rp [f] ;
+                fr.gpuF = F0 + FOff [k] ;
+                fr.cpuR = NULL ;                    // R is packed on the device, see below
+                fr.is_sparse = 1 ;
+                fr.nc = (int32_t) (Childp [f+1] - Childp [f]) ;
+                fr.Scount = S_count (f) ;
+                fr.gpuS = S0 + SOff [k] ;
+                fr.cn = (int32_t) (fn - fp) ;
+                fr.cm = (int32_t) Cm [f] ;
+                if (parent_here)
+                {
+                    fr.pn = (int32_t) pitch [pid] ;
+                    fr.gpuRjmap = (int32_t *) dRjmap.p + S->RjmapOffsets [f] ;
+                    fr.gpuRimap = (int32_t *) dRimap.p + S->RimapOffsets [f] ;
+                    fr.gpuC = fr.gpuF + frank * pitch [f] + fp ;
+                }
+                else if (pid < nf)
+                {
+                    fr.is_staged = 1 ;      // the parent is factorized in a later stage or elsewhere
+                }
+
+                // children from outside the group: their compact C blocks sit right behind the front
+                Long child_off = FOff [k] + fm * pitch [f] ;
+                for (Long cp = Childp [f] ; cp < Childp [f+1] ; cp++)
+                {
+                    const Long c = Child [cp] ;
+                    if (in_group (c)) continue ;
                     const Long ccn = (Rp [c+1] - Rp [c]) - (Super [c+1] - Super [c]) ;
                     const Long ccm = Cm [c] ;
                     gpuqr_front &ch = fronts [next_child] ;
                     memset (&ch, 0, sizeof (ch)) ;
-                    ch.fids = next_child ; ch.pids = rel ; ch.fidg = c ; ch.pidg = f ;
+                    ch.fids = next_child ; ch.pids = k ; ch.fidg = c ; ch.pidg = f ;
                     ch.fm = ccm ; ch.fn = ccn ; ch.fp = 0 ; ch.rank = 0 ; ch.ldn = ccn ;
                     ch.is_sparse = 1 ; ch.push_only = 1 ;
-                    ch.pn = (int32_t) fn ; ch.cm = (int32_t) ccm ; ch.cn = (int32_t) ccn ;
-                    ch.gpuRimap = dRimap + S->RimapOffsets [c] ;
-                    ch.gpuRjmap = dRjmap + S->RjmapOffsets [c] ;
-                    ch.gpuF = ch.gpuC = dF + child_off ;
+                    ch.pn = (int32_t) pitch [f] ; ch.cm = (int32_t) ccm ; ch.cn = (int32_t) ccn ;
+                    ch.gpuRimap = (int32_t *) dRimap.p + S->RimapOffsets [c] ;
+                    ch.gpuRjmap = (int32_t *) dRjmap.p + S->RjmapOffsets [c] ;
+                    ch.gpuF = ch.gpuC = F0 + child_off ;
                     if (ccm * ccn > 0)
                     {
-                        if (!limbo [c]) { code = 2 ; goto done ; }
-                        HIPCHK (hipMemcpy (ch.gpuF, limbo [c], (size_t) (ccm * ccn) * sizeof (double), hipMemcpyHostToDevice)) ;
+                        const double *src = mine ? (limbo_in ? limbo_in [c] : NULL) : limbo [c] ;
+                        if (!src) { code = mine ? 3 : 2 ; goto done ; }
+                        HIPCHK (hipMemcpy (ch.gpuF, src, (size_t) (ccm * ccn) * sizeof (double), hipMemcpyHostToDevice)) ;
                     }
-                    free (limbo [c]) ; limbo [c] = NULL ;
+                    if (!mine) { free (limbo [c]) ; limbo [c] = NULL ; }
                     child_off += ccm * ccn ;
+                    child_off += (child_off & 1) ;
                     next_child++ ;
                 }
             }
-
+            HIPCHK (hipStreamSynchronize (0)) ;
             TICK ("stage setup (memset, S, fronts)") ;
+
             // ---- the device work ---------------------------------------------------------------
             gpuqr_stats stats ;
-            int ecode = gpuqr_factor_sparse (S->gpuMemorySize, fronts, next_child, Parent, Childp, Child, &stats) ;
+            int ecode = gpuqr_factor_sparse (S->gpuMemorySize, fronts.data ( ), next_child, Parent, Childp, Child, &stats) ;
             TICK ("engine") ;
             if (ecode != GPUQR_SUCCESS) { code = (ecode == GPUQR_OUTOFMEMORY) ? 1 : 2 ; goto done ; }
             num->gpuKernelTime += stats.kernelTime ;
@@ -419,44 +493,61 @@ extern "C" int spqrgpu_amd_factorize
             num->gpuNumKernelLaunches += stats.numLaunches ;
             num->numStagesRun++ ;
 
-            // ---- R onto the stack (column-packed), staged C blocks into limbo ---------------------
+            // ---- R: packed on the device, one copy onto the stack ---------------------------------
             {
-                std::vector<Long> roff ((size_t) numFronts + 1) ;
-                roff [0] = rhead ;
-                for (Long p = sStart ; p < sEnd ; p++)
+                ptasks.assign ((size_t) numFronts, PackRTask ( )) ;
+                prefix.assign ((size_t) numFronts + 1, 0) ;
+                for (Long k = 0 ; k < numFronts ; k++)
                 {
-                    const Long f = Post [p] ;
+                    const Long f = list [k] ;
                     const Long fn = Rp [f+1] - Rp [f] ;
                     const Long frank = std::min (Fm [f], Super [f+1] - Super [f]) ;
-                    num->Rblock [f] = roff [p - sStart] ;
-                    roff [p - sStart + 1] = roff [p - sStart] + r_block_size (fn, frank) ;
+                    PackRTask &pt = ptasks [k] ;
+                    pt.F = F0 + FOff [k] ; pt.out = (double *) dR.p + ROff [k] ;
+                    pt.ld = (int32_t) pitch [f] ; pt.fn = (int32_t) fn ; pt.frank = (int32_t) frank ; pt.pad = 0 ;
+                    prefix [k+1] = prefix [k] + (frank + 31) / 32 ;
+                    num->Rblock [f] = rhead + ROff [k] ;
                 }
-                rhead = roff [numFronts] ;
-                std::atomic<int> oom (0) ;
-                parallel_for (numFronts, [&] (Long k)
+                if (dTasks.ensure ((size_t) numFronts * sizeof (PackRTask)) != hipSuccess) { code = 1 ; goto done ; }
+                if (dPrefix.ensure ((size_t) (numFronts + 1) * sizeof (long long)) != hipSuccess) { code = 1 ; goto done ; }
+                HIPCHK (hipMemcpyAsync (dTasks.p, ptasks.data ( ), (size_t) numFronts * sizeof (PackRTask), hipMemcpyHostToDevice, 0)) ;
+                HIPCHK (hipMemcpyAsync (dPrefix.p, prefix.data ( ), (size_t) (numFronts + 1) * sizeof (long long), hipMemcpyHostToDevice, 0)) ;
+                HIPCHK (qr_launch_pack_r ((const QrPackRTask *) dTasks.p, (const long long *) dPrefix.p, (int) numFronts, prefix [numFronts], 0)) ;
+                if (rsum > 0)
+                    HIPCHK (hipMemcpyAsync (num->Rstack + rhead, dR.p, (size_t) rsum * sizeof (double), hipMemcpyDeviceToHost, 0)) ;
+                rhead += rsum ;
+
+                // contribution blocks that leave the group: compact cm-by-cn, zero below the diagonal
+                for (Long k = 0 ; k < numFronts ; k++)
                 {
-                    const Long f = Post [sStart + k] ;
+                    if (!fronts [k].is_staged) continue ;
+                    const Long f = list [k] ;
                     const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
                     const Long frank = std::min (fm, fp) ;
-                    const double *cpuF = fronts [k].cpuR ;
-                    pack_r_block (cpuF, fn, frank, num->Rstack + roff [k]) ;
-                    if (fronts [k].is_staged)
+                    const Long cn = fn - fp, cm = mine ? Cm [f] : std::min (fm - frank, cn) ;
+                    double *L ;
+                    if (mine) { L = num->Cstack + chead ; num->Cblock [f] = chead ; chead += Cm [f] * cn ; }
+                    else
                     {
-                        const Long cn = fn - fp, cm = std::min (fm - frank, cn) ;
-                        const double *C = cpuF + frank * fn + fp ;
-                        double *L = (double *) calloc ((size_t) std::max ((Long) 1, cm * cn), sizeof (double)) ;
-                        if (!L) { oom = 1 ; return ; }
-                        for (Long i = 0 ; i < cm ; i++) for (Long j = i ; j < cn ; j++) L [i*cn + j] = C [i*fn + j] ;
+                        L = (double *) calloc ((size_t) std::max ((Long) 1, cm * cn), sizeof (double)) ;
+                        if (!L) { code = 1 ; goto done ; }
                         limbo [f] = L ;
                     }
-                }) ;
-                if (oom) { code = 1 ; goto done ; }
-                for (Long p = sStart ; p < sEnd ; p++)
+                    if (cm > 0 && cn > 0)
+                    {
+                        HIPCHK (hipMemcpy2D (L, (size_t) cn * sizeof (double), fronts [k].gpuF + frank * pitch [f] + fp,
+                            (size_t) pitch [f] * sizeof (double), (size_t) cn * sizeof (double), (size_t) cm, hipMemcpyDeviceToHost)) ;
+                        for (Long i = 1 ; i < cm ; i++) for (Long j = 0 ; j < std::min (i, cn) ; j++) L [i*cn + j] = 0 ;
+                    }
+                }
+                HIPCHK (hipStreamSynchronize (0)) ;
+
+                for (Long k = 0 ; k < numFronts ; k++)
                 {
-                    const Long f = Post [p] ;
+                    const Long f = list [k] ;
                     const Long fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
                     // assembly traffic: 24 B per S entry, 16 B per C entry + 4 B per map int
-                    num->assembleBytes += 24.0 * (double) fronts [p - sStart].Scount ;
+                    num->assembleBytes += 24.0 * (double) fronts [k].Scount ;
                     if (Cm [f] > 0 && fn - fp > 0 && Parent [f] < nf)
                     {
                         const double cmm = (double) Cm [f], cnn = (double) (fn - fp) ;
@@ -464,17 +555,16 @@ extern "C" int spqrgpu_amd_factorize
                     }
                 }
             }
+            TICK ("R pack + copy") ;
         }
 
-        TICK ("R pack") ;
         // ---- ranks and dead columns (no rank detection on the device) ----------------------------
         for (Long f = 0 ; f < nf ; f++)
         {
             const Long fm = Fm [f], fp = Super [f+1] - Super [f] ;
             const Long frank = std::min (fm, fp) ;
             for (Long k = fm ; k < fp ; k++) num->Rdead [Super [f] + k] = 1 ;      // pivot columns past the bottom
-            num->sumfrank += frank ;
-            num->maxfrank = std::max (num->maxfrank, frank) ;
+            if (is_mine (f)) { num->sumfrank += frank ; num->maxfrank = std::max (num->maxfrank, frank) ; }
         }
     }
     catch (std::bad_alloc &)
@@ -484,16 +574,20 @@ extern "C" int spqrgpu_amd_factorize
 
 done:
     for (size_t i = 0 ; i < limbo.size ( ) ; i++) free (limbo [i]) ;
-    free (fronts) ;
-    if (dF) (void) hipFree (dF) ;
-    if (dS) (void) hipFree (dS) ;
-    if (dRimap) (void) hipFree (dRimap) ;
-    if (dRjmap) (void) hipFree (dRjmap) ;
-    if (hR [0]) (void) hipHostFree (hR [0]) ;
-    if (hS) (void) hipHostFree (hS) ;
     if (code != 0) { spqr_amd_numeric_free (num) ; return code ; }
     *num_out = num ;
     return 0 ;
+}
+
+// One call = the whole numeric factorization of A = Q R on the device, stage by stage.
+extern "C" int spqrgpu_amd_factorize
+(
+    const spqr_amd_symbolic *S, const int64_t *Ap, const int64_t *Ai, const double *Ax,
+    spqr_amd_numeric **num_out
+)
+{
+    if (!S || !Ap || !Ax || !num_out) return 3 ;
+    return factorize_impl (S, Ap, Ai, Ax, NULL, NULL, num_out) ;
 }
 
 // R blocks -> compressed-column R (the R-only part of spqr_rcount / spqr_rconvert,
@@ -564,221 +658,5 @@ extern "C" int spqrgpu_amd_factorize_subset
 )
 {
     if (!S || !Ap || !Ax || !mine || !num_out) return 3 ;
-    *num_out = NULL ;
-    int code = 0 ;
-    const Long nf = S->nf, n = S->n, m = S->m ;
-    const Long *Super = S->Super.data ( ), *Rp = S->Rp.data ( ), *Post = S->Post.data ( ) ;
-    const Long *Parent = S->Parent.data ( ), *Childp = S->Childp.data ( ), *Child = S->Child.data ( ) ;
-    const Long *Fm = S->Fm.data ( ), *Cm = S->Cm.data ( ), *Sleft = S->Sleft.data ( ), *Sp = S->Sp.data ( ) ;
-
-    spqr_amd_numeric *num = (spqr_amd_numeric *) calloc (1, sizeof (spqr_amd_numeric)) ;
-    if (!num) return 1 ;
-    double *dF = NULL ; gpuqr_sentry *dS = NULL ; int32_t *dRimap = NULL, *dRjmap = NULL ;
-    double *hR = NULL ; gpuqr_sentry *hS = NULL ;
-    gpuqr_front *fronts = NULL ;
-
-    try
-    {
-        // ---- layout of this process's arena -----------------------------------------------
-        std::vector<Long> rel (nf, -1), FOff (nf, 0), ROff (nf, 0), SOff (nf, 0), SGlob (nf + 1, 0) ;
-        Long nmine = 0, nlimbo = 0 ;
-        size_t fsum = 0, rsum = 0, ssum = 0, rpack = 0, cpack = 0 ;
-        {
-            Long sacc = 0 ;
-            for (Long k = 0 ; k < nf ; k++)          // packed S is laid out front after front in postorder
-            {
-                const Long f = Post [k] ;
-                SGlob [f] = sacc ;
-                sacc += std::max ((Long) 0, Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]]) ;
-            }
-        }
-        for (Long k = 0 ; k < nf ; k++)
-        {
-            const Long f = Post [k] ;
-            if (!mine [f]) continue ;
-            const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
-            const Long frank = std::min (fm, fp) ;
-            rel [f] = nmine++ ;
-            FOff [f] = (Long) fsum ; ROff [f] = (Long) rsum ; SOff [f] = (Long) ssum ;
-            fsum += (size_t) (fm * fn) ;
-            for (Long cp = Childp [f] ; cp < Childp [f+1] ; cp++)
-            {
-                const Long c = Child [cp] ;
-                if (mine [c]) continue ;
-                nlimbo++ ;
-                fsum += (size_t) (Cm [c] * ((Rp [c+1] - Rp [c]) - (Super [c+1] - Super [c]))) ;
-            }
-            rsum += (size_t) ((frank + Cm [f]) * fn) ;
-            ssum += (size_t) std::max ((Long) 0, Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]]) ;
-            rpack += (size_t) (frank*(frank+1)/2 + frank*(fn-frank)) ;
-            if (Parent [f] < nf && !mine [Parent [f]]) cpack += (size_t) (Cm [f] * (fn - fp)) ;
-        }
-
-        num->nf = nf ;
-        num->rsize = (Long) rpack ;
-        num->Rstack = (double *) malloc (std::max ((size_t) 1, rpack) * sizeof (double)) ;
-        num->Rblock = (Long *) malloc (std::max ((Long) 1, nf) * sizeof (Long)) ;
-        num->Rdead = (char *) calloc (std::max ((Long) 1, n), 1) ;
-        num->Cstack = (double *) calloc (std::max ((size_t) 1, cpack), sizeof (double)) ;
-        num->Cblock = (Long *) malloc (std::max ((Long) 1, nf) * sizeof (Long)) ;
-        if (!num->Rstack || !num->Rblock || !num->Rdead || !num->Cstack || !num->Cblock) { code = 1 ; goto done ; }
-        for (Long f = 0 ; f < nf ; f++) { num->Rblock [f] = -1 ; num->Cblock [f] = -1 ; }
-
-        // ---- S values, maps, packed S (whole problem: pattern work only) ---------------------
-        std::vector<double> Sx ((size_t) S->anz) ;
-        {
-            std::vector<Long> w (Sp, Sp + m) ;
-            for (Long k = 0 ; k < n ; k++)
-            {
-                const Long col = S->Qfill [k] ;
-                for (Long p = Ap [col] ; p < Ap [col+1] ; p++) Sx [w [S->PLinv [Ai [p]]]++] = Ax [p] ;
-            }
-        }
-        const Long RimapSize = std::max ((Long) 1, S->RimapSize), RjmapSize = std::max ((Long) 1, S->RjmapSize) ;
-        std::vector<Long> Stair ((size_t) std::max ((Long) 1, Rp [nf])), Fmap ((size_t) std::max ((Long) 1, n)) ;
-        std::vector<int32_t> Rimap ((size_t) RimapSize), Rjmap ((size_t) RjmapSize) ;
-        std::vector<gpuqr_sentry> allS ((size_t) std::max ((Long) 1, S->anz)) ;
-        spqrgpu_amd_build_assembly_maps (nf, n, Fmap.data ( ), Post, Super, Rp, S->Rj.data ( ), Sleft, Sp,
-            S->Sj.data ( ), Sx.data ( ), Fm, Cm, Childp, Child, Stair.data ( ), Rjmap.data ( ),
-            S->RjmapOffsets.data ( ), Rimap.data ( ), S->RimapOffsets.data ( ), allS.data ( )) ;
-
-        if (nmine > 0)
-        {
-            if (hipHostMalloc ((void **) &hS, std::max ((size_t) 1, ssum) * sizeof (gpuqr_sentry), hipHostMallocDefault) != hipSuccess) { hS = NULL ; code = 1 ; goto done ; }
-            for (Long f = 0 ; f < nf ; f++)
-            {
-                if (!mine [f]) continue ;
-                const Long cnt = std::max ((Long) 0, Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]]) ;
-                if (cnt > 0) memcpy (hS + SOff [f], allS.data ( ) + SGlob [f], (size_t) cnt * sizeof (gpuqr_sentry)) ;
-            }
-            if (hipMalloc ((void **) &dRimap, RimapSize * sizeof (int32_t)) != hipSuccess) { dRimap = NULL ; code = 1 ; goto done ; }
-            if (hipMalloc ((void **) &dRjmap, RjmapSize * sizeof (int32_t)) != hipSuccess) { dRjmap = NULL ; code = 1 ; goto done ; }
-            HIPCHK (hipMemcpy (dRimap, Rimap.data ( ), RimapSize * sizeof (int32_t), hipMemcpyHostToDevice)) ;
-            HIPCHK (hipMemcpy (dRjmap, Rjmap.data ( ), RjmapSize * sizeof (int32_t), hipMemcpyHostToDevice)) ;
-            if (hipMalloc ((void **) &dF, std::max ((size_t) 1, fsum) * sizeof (double)) != hipSuccess) { dF = NULL ; code = 1 ; goto done ; }
-            if (hipMalloc ((void **) &dS, std::max ((size_t) 1, ssum) * sizeof (gpuqr_sentry)) != hipSuccess) { dS = NULL ; code = 1 ; goto done ; }
-            if (hipHostMalloc ((void **) &hR, std::max ((size_t) 1, rsum) * sizeof (double), hipHostMallocDefault) != hipSuccess) { hR = NULL ; code = 1 ; goto done ; }
-            fronts = (gpuqr_front *) malloc ((size_t) (nmine + nlimbo) * sizeof (gpuqr_front)) ;
-            if (!fronts) { code = 1 ; goto done ; }
-            HIPCHK (hipMemset (dF, 0, std::max ((size_t) 1, fsum) * sizeof (double))) ;
-            if (ssum > 0) HIPCHK (hipMemcpy (dS, hS, ssum * sizeof (gpuqr_sentry), hipMemcpyHostToDevice)) ;
-
-            Long next_child = nmine ;
-            for (Long f = 0 ; f < nf ; f++)
-            {
-                if (!mine [f]) continue ;
-                const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
-                const Long frank = std::min (fm, fp) ;
-                const Long pid = Parent [f] ;
-                const bool parent_mine = (pid < nf && mine [pid]) ;
-                gpuqr_front &fr = fronts [rel [f]] ;
-                memset (&fr, 0, sizeof (fr)) ;
-                fr.fids = rel [f] ; fr.pids = parent_mine ? rel [pid] : -1 ; fr.fidg = f ; fr.pidg = pid ;
-                fr.fm = fm ; fr.fn = fn ; fr.fp = fp ; fr.rank = frank ; fr.ldn = fn ;
-                fr.Stair = Stair.data ( ) + Rp [f] ;
-                fr.gpuF = dF + FOff [f] ;
-                fr.cpuR = hR + ROff [f] ;
-                fr.is_sparse = 1 ;
-                fr.nc = (int32_t) (Childp [f+1] - Childp [f]) ;
-                fr.Scount = std::max ((Long) 0, Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]]) ;
-                fr.gpuS = dS + SOff [f] ;
-                fr.cn = (int32_t) (fn - fp) ; fr.cm = (int32_t) Cm [f] ;
-                if (parent_mine)
-                {
-                    fr.pn = (int32_t) (Rp [pid+1] - Rp [pid]) ;
-                    fr.gpuRjmap = dRjmap + S->RjmapOffsets [f] ;
-                    fr.gpuRimap = dRimap + S->RimapOffsets [f] ;
-                    fr.gpuC = fr.gpuF + frank * fn + fp ;
-                }
-                else if (pid < nf)
-                {
-                    fr.is_staged = 1 ;
-                }
-                Long child_off = FOff [f] + fm * fn ;
-                for (Long cp = Childp [f] ; cp < Childp [f+1] ; cp++)
-                {
-                    const Long c = Child [cp] ;
-                    if (mine [c]) continue ;
-                    const Long ccn = (Rp [c+1] - Rp [c]) - (Super [c+1] - Super [c]) ;
-                    const Long ccm = Cm [c] ;
-                    gpuqr_front &ch = fronts [next_child] ;
-                    memset (&ch, 0, sizeof (ch)) ;
-                    ch.fids = next_child ; ch.pids = rel [f] ; ch.fidg = c ; ch.pidg = f ;
-                    ch.fm = ccm ; ch.fn = ccn ; ch.ldn = ccn ;
-                    ch.is_sparse = 1 ; ch.push_only = 1 ;
-                    ch.pn = (int32_t) fn ; ch.cm = (int32_t) ccm ; ch.cn = (int32_t) ccn ;
-                    ch.gpuRimap = dRimap + S->RimapOffsets [c] ;
-                    ch.gpuRjmap = dRjmap + S->RjmapOffsets [c] ;
-                    ch.gpuF = ch.gpuC = dF + child_off ;
-                    if (ccm * ccn > 0)
-                    {
-                        if (!limbo_in || !limbo_in [c]) { code = 3 ; goto done ; }
-                        HIPCHK (hipMemcpy (ch.gpuF, limbo_in [c], (size_t) (ccm * ccn) * sizeof (double), hipMemcpyHostToDevice)) ;
-                    }
-                    child_off += ccm * ccn ;
-                    next_child++ ;
-                }
-            }
-
-            gpuqr_stats stats ;
-            int ecode = gpuqr_factor_sparse (S->gpuMemorySize, fronts, next_child, Parent, Childp, Child, &stats) ;
-            if (ecode != GPUQR_SUCCESS) { code = (ecode == GPUQR_OUTOFMEMORY) ? 1 : 2 ; goto done ; }
-            num->gpuKernelTime = stats.kernelTime ;
-            num->gpuFlops = stats.flopsActual ;
-            num->gpuNumKernelLaunches = stats.numLaunches ;
-            num->numStagesRun = 1 ;
-
-            {
-                std::vector<Long> mylist, roff, coff ;
-                Long rhead = 0, chead = 0 ;
-                for (Long f = 0 ; f < nf ; f++)
-                {
-                    if (!mine [f]) continue ;
-                    const Long fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
-                    const Long frank = std::min (Fm [f], fp) ;
-                    mylist.push_back (f) ; roff.push_back (rhead) ; coff.push_back (chead) ;
-                    num->Rblock [f] = rhead ;
-                    rhead += r_block_size (fn, frank) ;
-                    if (fronts [rel [f]].is_staged) { num->Cblock [f] = chead ; chead += Cm [f] * (fn - fp) ; }
-                }
-                parallel_for ((Long) mylist.size ( ), [&] (Long k)
-                {
-                    const Long f = mylist [k] ;
-                    const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
-                    const Long frank = std::min (fm, fp) ;
-                    const double *cpuF = fronts [rel [f]].cpuR ;
-                    pack_r_block (cpuF, fn, frank, num->Rstack + roff [k]) ;
-                    if (fronts [rel [f]].is_staged)
-                    {
-                        const Long cn = fn - fp, cm = Cm [f] ;
-                        const double *C = cpuF + frank * fn + fp ;
-                        double *L = num->Cstack + coff [k] ;
-                        for (Long i = 0 ; i < cm ; i++) for (Long j = i ; j < cn ; j++) L [i*cn + j] = C [i*fn + j] ;
-                    }
-                }) ;
-            }
-        }
-        for (Long f = 0 ; f < nf ; f++)
-        {
-            const Long fm = Fm [f], fp = Super [f+1] - Super [f] ;
-            for (Long k = fm ; k < fp ; k++) num->Rdead [Super [f] + k] = 1 ;
-            if (mine [f]) { num->sumfrank += std::min (fm, fp) ; num->maxfrank = std::max (num->maxfrank, std::min (fm, fp)) ; }
-        }
-    }
-    catch (std::bad_alloc &)
-    {
-        code = 1 ;
-    }
-
-done:
-    free (fronts) ;
-    if (dF) (void) hipFree (dF) ;
-    if (dS) (void) hipFree (dS) ;
-    if (dRimap) (void) hipFree (dRimap) ;
-    if (dRjmap) (void) hipFree (dRjmap) ;
-    if (hR) (void) hipHostFree (hR) ;
-    if (hS) (void) hipHostFree (hS) ;
-    if (code != 0) { spqr_amd_numeric_free (num) ; return code ; }
-    *num_out = num ;
-    return 0 ;
+    return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in, num_out) ;
 }
