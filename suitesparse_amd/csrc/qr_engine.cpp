@@ -127,10 +127,23 @@ static int64_t *find_staircase_ld (const double *F, int64_t fm, int64_t fn, int6
 // schedule
 // -----------------------------------------------------------------------------
 
+// Stream classes.  Every launch goes to the stream of its class; launches of one class run in
+// round order, and a launch waits for the other classes only as far back as its tasks depend on
+// them, so the three streams drift apart as far as the data dependencies allow.
+//   0  critical path of a front: panel factorizations and the updates of the next panel's columns
+//   1  bulk updates by 256-row tasks (the bandwidth carrier)
+//   2  bulk updates by the smaller row tiers, S-assembly and pack-assembly
+#define QR_NCLASS 3
+// launch slots of a round: 0..3 factorize tiers, 4..7 bulk apply tiers, 8 assembly, 9..12 apply tiers
+// on the critical path
+#define QR_NSLOTS 13
+
 struct SchedTask
 {
     QrTask  t ;
     int32_t round ;
+    int32_t slot ;      // launch slot within the round
+    int32_t dep [QR_NCLASS] ;   // latest round of each class that this task needs finished (-1: none)
     int64_t vt ;        // VT tile index or -1
     int32_t nblk ;      // workgroups this task is run by (apply: column blocks; else 1)
     int32_t wait_ctr ;  // work queue: counter (= front) whose earlier rounds this task waits for
@@ -151,10 +164,6 @@ static int engine_mode (void)
     if (g_mode < 0) { const char *e = getenv ("GPUQR_MODE") ; g_mode = e ? atoi (e) : 0 ; }
     return g_mode ;
 }
-
-// Start rounds of childless fronts can be spread over this many rounds so that panel and apply
-// kernels of different fronts overlap; measured slower than starting them together, so off.
-static const int g_stagger = 1 ;
 
 struct KernelProfile { double ms, flops, bytes ; int64_t launches, tasks ; } ;
 static int g_profile_on = 0 ;
@@ -208,27 +217,49 @@ static inline int64_t flops_apply (int64_t K, int64_t w, int64_t n)
 
 struct Seg { int32_t row, n ; } ;
 
-// Emit all factorize/apply tasks of one front.  Returns the last round used.
-static int32_t plan_front
+static inline int slot_class (int slot)
+{
+    return (slot < 4 || slot >= 9) ? 0 : ((slot == 7) ? 1 : 2) ;
+}
+static inline int slot_kernel (int slot) { return (slot < 9) ? slot : slot - 5 ; }
+
+// Look-ahead: trailing widths from this many column tiles up get a separate update task for the
+// columns of the next panel, which runs on the critical stream ahead of the bulk of the update.
+// Off by default: at 50-60 us per panel step the three extra launches on the critical path cost
+// more than the overlap returns (one 4096 x 2048 front: 16.0 ms with, 13.8 ms without; four
+// 8192 x 4096 fronts: 55.7 ms with, 56.7 ms without).  GPUQR_LOOKAHEAD_TILES=n turns it on.
+static int lookahead_min_tiles (void)
+{
+    static int v = -1 ;
+    if (v < 0) { const char *e = getenv ("GPUQR_LOOKAHEAD_TILES") ; v = e ? atoi (e) : 0 ; if (v < 2) v = 1 << 30 ; }
+    return v ;
+}
+
+// Emit all factorize/apply tasks of one front.  last [c] is, on entry, the latest round of class c
+// whose work the front's first tasks must wait for (assembly into it), and on return the latest
+// round of class c used by the front.  Every task gets round = 1 + the latest round it depends on.
+static void plan_front
 (
     Plan &plan, double *F, int64_t fm, int64_t fn, int64_t ld, const int64_t *Stair,
-    int32_t start_round, bool emit
+    int32_t last [QR_NCLASS], bool emit
 )
 {
-    int32_t done = start_round - 1 ;
-    if (fm <= 0 || fn <= 0) return done ;
+    if (fm <= 0 || fn <= 0) return ;
     const int64_t mn = (fm < fn) ? fm : fn ;
     const int64_t npanels = (mn + QR_PANEL_W - 1) / QR_PANEL_W ;
     const int64_t ntiles  = (fn + QR_PANEL_W - 1) / QR_PANEL_W ;
-    hvec<int32_t> tileround ((size_t) ntiles, start_round - 1) ;
+    // latest round of each class that wrote column tile t
+    hvec<int32_t> lastw [QR_NCLASS] ;
+    for (int c = 0 ; c < QR_NCLASS ; c++) lastw [c].assign ((size_t) ntiles, last [c]) ;
     hvec<Seg> tops, next ;
-    hvec<int64_t> level_first, level_count ;      // index ranges into plan.tasks per level
     int64_t e_prev = 0 ;
+    const int la_min = lookahead_min_tiles ( ) ;
 
     for (int64_t p = 0 ; p < npanels ; p++)
     {
         const int64_t c0 = p * QR_PANEL_W ;
         const int64_t w = (fn - c0 < QR_PANEL_W) ? (fn - c0) : QR_PANEL_W ;
+        // rows [r0, e) take part: r0 = c0 (everything above is final R), e from the staircase
         const int64_t r0 = c0 ;
         int64_t e = fm ;
         if (Stair != NULL)
@@ -249,7 +280,9 @@ static int32_t plan_front
         tops.clear ( ) ;
         const int64_t nchunks = (m + QR_MAX_K - 1) / QR_MAX_K ;
         int32_t level = 0 ;
-        const int32_t rF0 = tileround [p] + 1 ;
+        int32_t depF [QR_NCLASS] ;
+        int32_t rF0 = 0 ;
+        for (int c = 0 ; c < QR_NCLASS ; c++) { depF [c] = lastw [c][p] ; rF0 = std::max (rF0, depF [c] + 1) ; }
         for (int64_t c = 0 ; c < nchunks ; c++)
         {
             FRef fr ;
@@ -295,62 +328,84 @@ static int32_t plan_front
             pt.K = fr.K ; pt.nseg = fr.nseg ; pt.c_begin = pt.c_end = 0 ;
             for (int s = 0 ; s < fr.nseg ; s++) { pt.seg_row [s] = fr.segs [s].row ; pt.seg_n [s] = fr.segs [s].n ; }
             st.round = rF0 + fr.level ;
+            st.slot = st.t.tier ;
+            for (int c = 0 ; c < QR_NCLASS ; c++) st.dep [c] = depF [c] ;
+            if (fr.level > 0) st.dep [0] = rF0 + fr.level - 1 ;
             st.vt = fr.vt ;
             st.nblk = 1 ;
             st.flops = (double) flops_factorize (fr.K, w, trailing) ;
             st.bytes = 16.0 * fr.K * w + (trailing ? 8.0 * QR_VT_DOUBLES : 0.0) ;
             plan.tasks.push_back (st) ;
         }
-        done = std::max (done, rF0 + nlevels - 1) ;
-        tileround [p] = rF0 + nlevels - 1 ;
+        lastw [0][p] = rF0 + nlevels - 1 ;
+        last [0] = std::max (last [0], rF0 + nlevels - 1) ;
 
         // ---- apply tasks ---------------------------------------------------------
         if (trailing)
         {
-            // All trailing tiles carry the same round number (they were all updated by the same
-            // rounds of the previous panel), so one apply task per factorize task covers the whole
-            // trailing width; the kernel cuts it into column blocks, one workgroup each.
+            // One apply task per factorize task and column range; the kernel cuts a range into
+            // column blocks, one workgroup each.  A wide trailing matrix is cut in two ranges: the
+            // next panel's tile, updated on the critical stream so that the next factorization can
+            // start at once, and the rest.
             const int64_t t0 = p + 1 ;
-            int64_t bt = 4 ;                    // column tiles per workgroup: 128 columns (64 and 256 measured slower)
-            while ((int64_t) frefs.size ( ) * ((ntiles - t0 + bt - 1) / bt) > 16384 && bt < 64) bt *= 2 ;
-            const int64_t cb = t0 * QR_PANEL_W ;
-            const int64_t ce = fn ;
-            const int64_t nblk = (ntiles - t0 + bt - 1) / bt ;
-            int32_t ready = tileround [t0] ;
-            for (int64_t t = t0 ; t < ntiles ; t++) ready = std::max (ready, tileround [t]) ;
-            for (int32_t lv = 0 ; lv < nlevels ; lv++)
+            const bool split = (p + 1 < npanels) && (ntiles - t0 >= la_min) ;
+            for (int part = 0 ; part < (split ? 2 : 1) ; part++)
             {
-                const int32_t round = std::max (ready, rF0 + lv) + 1 ;
-                for (size_t i = 0 ; i < frefs.size ( ) ; i++)
+                const bool critical = split && part == 0 ;
+                const int64_t ta = (split && part == 1) ? t0 + 1 : t0 ;             // first tile
+                const int64_t tb = critical ? t0 + 1 : ntiles ;                     // one past the last
+                const int64_t bt = critical ? 1 : 4 ;   // column tiles per workgroup: 128 columns (64 and 256 measured slower)
+                const int64_t cb = ta * QR_PANEL_W ;
+                const int64_t ce = std::min (tb * QR_PANEL_W, fn) ;
+                const int64_t nblk = (tb - ta + bt - 1) / bt ;
+                for (int32_t lv = 0 ; lv < nlevels ; lv++)
                 {
-                    const FRef &fr = frefs [i] ;
-                    if (fr.level != lv) continue ;
-                    plan.flops += flops_apply (fr.K, w, ce - cb) ;
-                    if (!emit) continue ;
-                    SchedTask st ;
-                    memset (&st, 0, sizeof (st)) ;
-                    st.t.type = QR_TASK_APPLY ;
-                    st.t.tier = tier_of (fr.K) ;
-                    QrPanelTask &pt = st.t.u.panel ;
-                    pt.F = F ; pt.VT = NULL ; pt.ld = (int32_t) ld ; pt.col0 = (int32_t) c0 ; pt.w = (int32_t) w ;
-                    pt.K = fr.K ; pt.nseg = fr.nseg ; pt.c_begin = (int32_t) cb ; pt.c_end = (int32_t) ce ;
-                    pt.cb_cols = (int32_t) (bt * QR_PANEL_W) ;
-                    for (int s = 0 ; s < fr.nseg ; s++) { pt.seg_row [s] = fr.segs [s].row ; pt.seg_n [s] = fr.segs [s].n ; }
-                    st.round = round ;
-                    st.vt = fr.vt ;
-                    st.nblk = (int32_t) nblk ;
-                    st.flops = (double) flops_apply (fr.K, w, ce - cb) ;
-                    // A read + written once; V (K x 32) and the VT tile read once per workgroup
-                    st.bytes = 16.0 * fr.K * (double) (ce - cb) + (double) nblk * (8.0 * fr.K * w + 8.0 * QR_VT_DOUBLES) ;
-                    plan.tasks.push_back (st) ;
+                    // what this level's tasks wait for: the last writers of their columns, and the
+                    // factorize tasks of the level
+                    int32_t dep [QR_NCLASS] = {-1, -1, -1} ;
+                    for (int c = 0 ; c < QR_NCLASS ; c++)
+                        for (int64_t t = ta ; t < tb ; t++) dep [c] = std::max (dep [c], lastw [c][t]) ;
+                    dep [0] = std::max (dep [0], rF0 + lv) ;
+                    const int32_t round = 1 + std::max (dep [0], std::max (dep [1], dep [2])) ;
+                    int32_t used [QR_NCLASS] = {-1, -1, -1} ;
+                    for (size_t i = 0 ; i < frefs.size ( ) ; i++)
+                    {
+                        const FRef &fr = frefs [i] ;
+                        if (fr.level != lv) continue ;
+                        plan.flops += flops_apply (fr.K, w, ce - cb) ;
+                        const int tier = tier_of (fr.K) ;
+                        const int slot = critical ? 9 + tier : 4 + tier ;
+                        used [slot_class (slot)] = round ;
+                        if (!emit) continue ;
+                        SchedTask st ;
+                        memset (&st, 0, sizeof (st)) ;
+                        st.t.type = QR_TASK_APPLY ;
+                        st.t.tier = tier ;
+                        QrPanelTask &pt = st.t.u.panel ;
+                        pt.F = F ; pt.VT = NULL ; pt.ld = (int32_t) ld ; pt.col0 = (int32_t) c0 ; pt.w = (int32_t) w ;
+                        pt.K = fr.K ; pt.nseg = fr.nseg ; pt.c_begin = (int32_t) cb ; pt.c_end = (int32_t) ce ;
+                        pt.cb_cols = (int32_t) (bt * QR_PANEL_W) ;
+                        for (int s = 0 ; s < fr.nseg ; s++) { pt.seg_row [s] = fr.segs [s].row ; pt.seg_n [s] = fr.segs [s].n ; }
+                        st.round = round ;
+                        st.slot = slot ;
+                        for (int c = 0 ; c < QR_NCLASS ; c++) st.dep [c] = dep [c] ;
+                        st.vt = fr.vt ;
+                        st.nblk = (int32_t) nblk ;
+                        st.flops = (double) flops_apply (fr.K, w, ce - cb) ;
+                        // A read + written once; V (K x 32) and the VT tile read once per workgroup
+                        st.bytes = 16.0 * fr.K * (double) (ce - cb) + (double) nblk * (8.0 * fr.K * w + 8.0 * QR_VT_DOUBLES) ;
+                        plan.tasks.push_back (st) ;
+                    }
+                    for (int c = 0 ; c < QR_NCLASS ; c++)
+                    {
+                        if (used [c] < 0) continue ;
+                        for (int64_t t = ta ; t < tb ; t++) lastw [c][t] = used [c] ;
+                        last [c] = std::max (last [c], used [c]) ;
+                    }
                 }
-                ready = round ;
-                done = std::max (done, round) ;
             }
-            for (int64_t t = t0 ; t < ntiles ; t++) tileround [t] = ready ;
         }
     }
-    return done ;
 }
 
 extern "C" int64_t gpuqr_front_flops (int64_t fm, int64_t fn, const int64_t *Stair)
@@ -358,7 +413,7 @@ extern "C" int64_t gpuqr_front_flops (int64_t fm, int64_t fn, const int64_t *Sta
     try
     {
         Plan plan ;
-        plan_front (plan, NULL, fm, fn, fn, Stair, 1, false) ;
+        { int32_t last [QR_NCLASS] = {-1, -1, -1} ; plan_front (plan, NULL, fm, fn, fn, Stair, last, false) ; }
         return plan.flops ;
     }
     catch (std::bad_alloc &) { return -1 ; }
@@ -382,7 +437,7 @@ extern "C" int64_t gpuqr_front_flops (int64_t fm, int64_t fn, const int64_t *Sta
 struct DeviceCache
 {
     bool ready = false ;
-    hipStream_t sCompute = NULL, sApply = NULL, sCopy = NULL ;
+    hipStream_t sCompute = NULL, sApply = NULL, sSmall = NULL, sCopy = NULL ;
     hipEvent_t evStart = NULL, evStop = NULL ;
     std::vector<hipEvent_t> evPool ;        // untimed events, reused by every call
     void *d_tasks = NULL, *d_refs = NULL, *d_vt = NULL, *h_stage = NULL, *d_counters = NULL ;
@@ -415,6 +470,7 @@ struct DeviceCache
     {
         if (sCompute) (void) hipStreamDestroy (sCompute) ;
         if (sApply) (void) hipStreamDestroy (sApply) ;
+        if (sSmall) (void) hipStreamDestroy (sSmall) ;
         if (sCopy) (void) hipStreamDestroy (sCopy) ;
         for (size_t i = 0 ; i < evPool.size ( ) ; i++) (void) hipEventDestroy (evPool [i]) ;
         if (evStart) (void) hipEventDestroy (evStart) ;
@@ -444,6 +500,8 @@ static DeviceCache *device_cache (void)
         if (hipDeviceGetStreamPriorityRange (&prio_lo, &prio_hi) != hipSuccess) { prio_lo = prio_hi = 0 ; }
         if (hipStreamCreateWithPriority (&dc->sCompute, hipStreamNonBlocking, prio_hi) != hipSuccess) { dc->release ( ) ; return NULL ; }
         if (hipStreamCreateWithPriority (&dc->sApply, hipStreamNonBlocking, prio_lo) != hipSuccess) { dc->release ( ) ; return NULL ; }
+        { const char *e = getenv ("GPUQR_STREAMS") ;
+          if (e && atoi (e) == 3 && hipStreamCreateWithPriority (&dc->sSmall, hipStreamNonBlocking, prio_lo) != hipSuccess) { dc->release ( ) ; return NULL ; } }
         if (hipStreamCreateWithFlags (&dc->sCopy, hipStreamNonBlocking) != hipSuccess) { dc->release ( ) ; return NULL ; }
         if (hipEventCreate (&dc->evStart) != hipSuccess) { dc->release ( ) ; return NULL ; }
         if (hipEventCreate (&dc->evStop) != hipSuccess) { dc->release ( ) ; return NULL ; }
@@ -521,7 +579,6 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
 
         // ---- children-first order from pids -----------------------------------------
         hvec<int64_t> nchild ((size_t) nf, 0), order ;
-        hvec<int32_t> child_pack_round ((size_t) nf, 0) ;   // max over children of their pack round
         for (int64_t f = 0 ; f < nf ; f++) if (fronts [f].pids >= 0) nchild [fronts [f].pids]++ ;
         order.reserve ((size_t) nf) ;
         {
@@ -540,14 +597,15 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
 
         // ---- build the schedule -----------------------------------------------------
         Plan plan ;
-        int64_t nleaf = 0 ;
-        hvec<int32_t> done_round ((size_t) nf, 0) ;
+        // per front: latest round of each class that assembled into it; latest round of each class it used
+        hvec<int32_t> in_last ((size_t) nf * QR_NCLASS, -1), done_last ((size_t) nf * QR_NCLASS, -1) ;
         for (size_t k = 0 ; k < order.size ( ) ; k++)
         {
             const int64_t f = order [k] ;
             gpuqr_front &fr = fronts [f] ;
-            int32_t done = 0 ;
             const size_t first_task = plan.tasks.size ( ) ;
+            int32_t last [QR_NCLASS] ;
+            for (int c = 0 ; c < QR_NCLASS ; c++) last [c] = in_last [f*QR_NCLASS + c] ;
             if (!(fr.is_sparse && fr.push_only))
             {
                 // S assembly, round 0
@@ -561,21 +619,17 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                         st.t.u.sasm.pstart = ps ;
                         st.t.u.sasm.pend = std::min (ps + (int64_t) QR_SASM_CHUNK, fr.Scount) ;
                         st.t.u.sasm.fn = (int32_t) fr.fn ; st.t.u.sasm.ld = (int32_t) front_pitch (fr) ;
-                        st.round = 0 ; st.vt = -1 ; st.nblk = 1 ;
+                        st.round = 0 ; st.slot = 8 ; st.vt = -1 ; st.nblk = 1 ;
+                        st.dep [0] = st.dep [1] = st.dep [2] = -1 ;
                         st.flops = 0 ;
                         st.bytes = 24.0 * (double) (st.t.u.sasm.pend - st.t.u.sasm.pstart) ;   // 16 read + 8 written
                         plan.tasks.push_back (st) ;
                     }
+                    if (fr.Scount > 0) last [2] = std::max (last [2], 0) ;
                 }
-                int32_t start = std::max (1, child_pack_round [f] + 1) ;
-                // fronts with no children would all start in round 1 and march in lockstep, every
-                // panel round of one coinciding with the panel rounds of the others; shifting their
-                // starts over a few rounds lets one front's updates overlap another's panels
-                if (child_pack_round [f] == 0 && g_stagger > 1) start += (int32_t) ((nleaf++) % g_stagger) ;
-                done = plan_front (plan, fr.gpuF, fr.fm, fr.fn, front_pitch (fr), fr.Stair, start, true) ;
-                if (done < start - 1) done = start - 1 ;
+                plan_front (plan, fr.gpuF, fr.fm, fr.fn, front_pitch (fr), fr.Stair, last, true) ;
             }
-            done_round [f] = done ;
+            for (int c = 0 ; c < QR_NCLASS ; c++) done_last [f*QR_NCLASS + c] = last [c] ;
             for (size_t i = first_task ; i < plan.tasks.size ( ) ; i++)
             {
                 plan.tasks [i].wait_ctr = (int32_t) f ; plan.tasks [i].signal_ctr = (int32_t) f ;
@@ -583,7 +637,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
             // pack assembly into the parent
             if (fr.is_sparse && fr.pids >= 0 && fr.cm > 0 && fr.cn > 0)
             {
-                const int32_t round = done + 1 ;
+                const int32_t round = 1 + std::max (last [0], std::max (last [1], last [2])) ;
                 const int32_t cld = fr.push_only ? fr.cn : (int32_t) front_pitch (fr) ;
                 for (int32_t ci = 0 ; ci < fr.cm ; ci += QR_PACK_TILE)
                 {
@@ -598,7 +652,8 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                         pk.pn = (int32_t) std::max<int64_t> (fr.pn, front_pitch (fronts [fr.pids])) ;
                         pk.cistart = ci ; pk.ciend = std::min (ci + QR_PACK_TILE, fr.cm) ;
                         pk.cjstart = cj ; pk.cjend = std::min (cj + QR_PACK_TILE, fr.cn) ;
-                        st.round = round ; st.vt = -1 ; st.nblk = 1 ;
+                        st.round = round ; st.slot = 8 ; st.vt = -1 ; st.nblk = 1 ;
+                        for (int c = 0 ; c < QR_NCLASS ; c++) st.dep [c] = last [c] ;
                         st.wait_ctr = (int32_t) f ; st.signal_ctr = (int32_t) fr.pids ;
                         {
                             // entries of the tile on or above the diagonal: 8 read + 8 written, plus the map ints
@@ -611,8 +666,9 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                         plan.tasks.push_back (st) ;
                     }
                 }
-                child_pack_round [fr.pids] = std::max (child_pack_round [fr.pids], round) ;
-                done_round [f] = round ;
+                int32_t &pl = in_last [fr.pids*QR_NCLASS + 2] ;
+                pl = std::max (pl, round) ;
+                done_last [f*QR_NCLASS + 2] = std::max (done_last [f*QR_NCLASS + 2], round) ;
             }
         }
 
@@ -620,13 +676,17 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
         int32_t nrounds = 0 ;
         for (int64_t i = 0 ; i < ntasks ; i++) nrounds = std::max (nrounds, plan.tasks [i].round + 1) ;
 
-        // counting sort of the workgroups by (round, kernel id): one launch per non-empty bucket
-        const int64_t nbuckets = (int64_t) nrounds * QR_NKERNELS ;
+        // counting sort of the workgroups by (round, launch slot): one launch per non-empty bucket
+        const int64_t nbuckets = (int64_t) nrounds * QR_NSLOTS ;
         hvec<int64_t> rptr ((size_t) nbuckets + 1, 0) ;
+        // latest round of each class that some task of the bucket depends on
+        hvec<int32_t> bdep ((size_t) nbuckets * QR_NCLASS, -1) ;
         for (int64_t i = 0 ; i < ntasks ; i++)
         {
             const SchedTask &st = plan.tasks [i] ;
-            rptr [(int64_t) st.round * QR_NKERNELS + qr_task_kernel_id (st.t.type, st.t.tier) + 1] += st.nblk ;
+            const int64_t b = (int64_t) st.round * QR_NSLOTS + st.slot ;
+            rptr [b + 1] += st.nblk ;
+            for (int c = 0 ; c < QR_NCLASS ; c++) bdep [b*QR_NCLASS + c] = std::max (bdep [b*QR_NCLASS + c], st.dep [c]) ;
         }
         for (int64_t b = 0 ; b < nbuckets ; b++) rptr [b+1] += rptr [b] ;
         const int64_t nrefs = rptr [nbuckets] ;
@@ -637,7 +697,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
             for (int64_t i = 0 ; i < ntasks ; i++)
             {
                 const SchedTask &st = plan.tasks [i] ;
-                const int64_t b = (int64_t) st.round * QR_NKERNELS + qr_task_kernel_id (st.t.type, st.t.tier) ;
+                const int64_t b = (int64_t) st.round * QR_NSLOTS + st.slot ;
                 bflops [b] += st.flops ; bbytes [b] += st.bytes ;
             }
         }
@@ -741,7 +801,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                         const int64_t last = cptr [c+1] - 1 ;
                         need = ccum [last] + plan.tasks [cidx [last]].nblk ;
                     }
-                    int64_t &q = pos [(int64_t) st.round * QR_NKERNELS + qr_task_kernel_id (st.t.type, st.t.tier)] ;
+                    int64_t &q = pos [(int64_t) st.round * QR_NSLOTS + st.slot] ;
                     for (int32_t b = 0 ; b < st.nblk ; b++)
                     {
                         QrQueueRef &qr = h_qrefs [q++] ;
@@ -822,7 +882,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                         if (!ok || acc != pt.K) { code = GPUQR_GPUERROR ; goto cleanup ; }
                     }
                     h_tasks [i] = st.t ;
-                    int64_t &q = pos [(int64_t) st.round * QR_NKERNELS + qr_task_kernel_id (st.t.type, st.t.tier)] ;
+                    int64_t &q = pos [(int64_t) st.round * QR_NSLOTS + st.slot] ;
                     for (int32_t b = 0 ; b < st.nblk ; b++) { h_refs [q].task = (int32_t) i ; h_refs [q].blk = b ; q++ ; }
                 }
             }
@@ -830,38 +890,73 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
             HIP_TRY (hipMemcpyAsync (d_refs, h_refs, ref_bytes, hipMemcpyHostToDevice, sCompute)) ;
 
             // ---- fronts grouped by the round after which their data is final -------------
+            auto final_round = [&] (int64_t f)
+            {
+                const int32_t *d = &done_last [f*QR_NCLASS] ;
+                return std::max (0, std::max (d [0], std::max (d [1], d [2]))) ;
+            } ;
             hvec<int64_t> pull_order ;
             for (int64_t f = 0 ; f < nf ; f++)
                 if (fronts [f].cpuR != NULL && !(fronts [f].is_sparse && fronts [f].push_only)) pull_order.push_back (f) ;
             std::sort (pull_order.begin ( ), pull_order.end ( ), [&] (int64_t a, int64_t b)
                 {
-                    int32_t ra = std::min (done_round [a], nrounds - 1), rb = std::min (done_round [b], nrounds - 1) ;
+                    int32_t ra = std::min (final_round (a), nrounds - 1), rb = std::min (final_round (b), nrounds - 1) ;
                     return (ra != rb) ? (ra < rb) : (a < b) ;
                 }) ;
 
-            // Two compute streams: factorize kernels on one, apply and assembly kernels on the
-            // other, so that the latency-bound panel tasks of a round overlap its bandwidth-bound
-            // updates.  Round r on either stream waits for round r-1 on the other.
+            // Three compute streams, one per class.  The launches of a class are queued in round
+            // order; before a launch its stream waits for the event of the latest round of each
+            // other class that the tasks of the launch depend on, and for nothing else.
+            // (classes 0 and 2 share a stream unless GPUQR_STREAMS=3: every stream costs the process a
+            // hardware queue, and with several processes on one device a fifth queue per process was
+            // seen to stall the whole device)
+            static int nstreams = 0 ;
+            if (nstreams == 0) { const char *e = getenv ("GPUQR_STREAMS") ; nstreams = (e && atoi (e) == 3) ? 3 : 2 ; }
+            // Class 2 joins the lighter of the two streams.  Rough launch times (us per 512 workgroups,
+            // measured): factorize 40/40/50/62 by tier, updates 12/17/28/80 by tier.
+            int small_on ;
+            {
+                static const double us [QR_NSLOTS] = {40, 40, 50, 62, 12, 17, 28, 80, 55, 12, 17, 28, 80} ;
+                double est [QR_NCLASS] = {0, 0, 0} ;
+                for (int64_t b = 0 ; b < nbuckets ; b++)
+                {
+                    const int64_t n = rptr [b+1] - rptr [b] ;
+                    if (n > 0) est [slot_class ((int) (b % QR_NSLOTS))] += us [b % QR_NSLOTS] * (double) ((n + 511) / 512) ;
+                }
+                small_on = est [1] < est [0] ;
+                const char *e = getenv ("GPUQR_SMALL_ON") ;
+                if (e) small_on = atoi (e) ;
+            }
+            hipStream_t cstream [QR_NCLASS] = {sCompute, sApply, (nstreams == 3) ? dc->sSmall : (small_on ? sApply : sCompute)} ;
             HIP_TRY (hipEventRecord (evStart, sCompute)) ;
-            HIP_TRY (hipStreamWaitEvent (sApply, evStart, 0)) ;        // the task upload
+            for (int c = 1 ; c < QR_NCLASS ; c++) HIP_TRY (hipStreamWaitEvent (cstream [c], evStart, 0)) ;    // the task upload
             size_t pi = 0, nev = 0 ;
-            hipEvent_t prevF = NULL, prevA = NULL ;
+            // evAt [c][r]: event recorded after the last launch of class c in the latest round <= r that had one
+            hvec<hipEvent_t> evAt [QR_NCLASS] ;
+            for (int c = 0 ; c < QR_NCLASS ; c++) evAt [c].assign ((size_t) nrounds, (hipEvent_t) NULL) ;
+            hipEvent_t waited [QR_NCLASS][QR_NCLASS] ;
+            for (int x = 0 ; x < QR_NCLASS ; x++) for (int y = 0 ; y < QR_NCLASS ; y++) waited [x][y] = NULL ;
+            static const int slot_order [QR_NSLOTS] = {0, 1, 2, 3, 9, 10, 11, 12, 7, 4, 5, 6, 8} ;
             for (int32_t r = 0 ; r < nrounds ; r++)
             {
-                bool hasF = false, hasA = false ;
-                for (int kid = 0 ; kid < QR_NKERNELS ; kid++)
+                bool launched [QR_NCLASS] = {false, false, false} ;
+                for (int si = 0 ; si < QR_NSLOTS ; si++)
                 {
-                    const int64_t b = (int64_t) r * QR_NKERNELS + kid ;
-                    if (rptr [b+1] > rptr [b]) { if (kid < 4) hasF = true ; else hasA = true ; }
-                }
-                if (hasF && prevA) HIP_TRY (hipStreamWaitEvent (sCompute, prevA, 0)) ;
-                if (hasA && prevF) HIP_TRY (hipStreamWaitEvent (sApply, prevF, 0)) ;
-                for (int kid = 0 ; kid < QR_NKERNELS ; kid++)
-                {
-                    const int64_t b = (int64_t) r * QR_NKERNELS + kid ;
+                    const int slot = slot_order [si] ;
+                    const int64_t b = (int64_t) r * QR_NSLOTS + slot ;
                     const int64_t n = rptr [b+1] - rptr [b] ;
                     if (n <= 0) continue ;
-                    hipStream_t st = (kid < 4) ? sCompute : sApply ;
+                    const int x = slot_class (slot), kid = slot_kernel (slot) ;
+                    hipStream_t st = cstream [x] ;
+                    for (int y = 0 ; y < QR_NCLASS ; y++)
+                    {
+                        const int32_t d = bdep [b*QR_NCLASS + y] ;
+                        if (y == x || d < 0 || cstream [y] == st) continue ;
+                        hipEvent_t ev = evAt [y][d] ;
+                        if (ev == NULL || ev == waited [x][y]) continue ;
+                        HIP_TRY (hipStreamWaitEvent (st, ev, 0)) ;
+                        waited [x][y] = ev ;
+                    }
                     if (g_profile_on)
                     {
                         hipEvent_t e0, e1 ;
@@ -876,25 +971,26 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                     {
                         HIP_TRY (qr_launch_tasks (kid, d_tasks, d_refs + rptr [b], (int) n, st)) ;
                     }
+                    launched [x] = true ;
                     launches++ ;
                 }
-                if (hasF)
+                for (int c = 0 ; c < QR_NCLASS ; c++)
                 {
-                    prevF = dc->pooled_event (nev++) ;
-                    if (!prevF) { code = GPUQR_GPUERROR ; goto cleanup ; }
-                    HIP_TRY (hipEventRecord (prevF, sCompute)) ;
+                    if (launched [c])
+                    {
+                        hipEvent_t ev = dc->pooled_event (nev++) ;
+                        if (!ev) { code = GPUQR_GPUERROR ; goto cleanup ; }
+                        HIP_TRY (hipEventRecord (ev, cstream [c])) ;
+                        evAt [c][r] = ev ;
+                        // a class that shares the stream is covered by the same event
+                        for (int c2 = 0 ; c2 < c ; c2++) if (cstream [c2] == cstream [c]) evAt [c2][r] = ev ;
+                    }
+                    else evAt [c][r] = (r > 0) ? evAt [c][r-1] : (hipEvent_t) NULL ;
                 }
-                if (hasA)
+                if (pi < pull_order.size ( ) && std::min (final_round (pull_order [pi]), nrounds - 1) <= r)
                 {
-                    prevA = dc->pooled_event (nev++) ;
-                    if (!prevA) { code = GPUQR_GPUERROR ; goto cleanup ; }
-                    HIP_TRY (hipEventRecord (prevA, sApply)) ;
-                }
-                if (pi < pull_order.size ( ) && std::min (done_round [pull_order [pi]], nrounds - 1) <= r)
-                {
-                    if (prevF) HIP_TRY (hipStreamWaitEvent (sCopy, prevF, 0)) ;
-                    if (prevA) HIP_TRY (hipStreamWaitEvent (sCopy, prevA, 0)) ;
-                    while (pi < pull_order.size ( ) && std::min (done_round [pull_order [pi]], nrounds - 1) <= r)
+                    for (int c = 0 ; c < QR_NCLASS ; c++) if (evAt [c][r]) HIP_TRY (hipStreamWaitEvent (sCopy, evAt [c][r], 0)) ;
+                    while (pi < pull_order.size ( ) && std::min (final_round (pull_order [pi]), nrounds - 1) <= r)
                     {
                         gpuqr_front &fr = fronts [pull_order [pi++]] ;
                         int64_t nrows = fr.rank ;
@@ -904,21 +1000,28 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                     }
                 }
             }
-            if (prevA) HIP_TRY (hipStreamWaitEvent (sCompute, prevA, 0)) ;
+            for (int c = 1 ; c < QR_NCLASS ; c++)
+                if (nrounds > 0 && evAt [c][nrounds-1]) HIP_TRY (hipStreamWaitEvent (sCompute, evAt [c][nrounds-1], 0)) ;
             HIP_TRY (hipEventRecord (evStop, sCompute)) ;
             HIP_TRY (hipStreamSynchronize (sCompute)) ;
             HIP_TRY (hipStreamSynchronize (sApply)) ;
+            if (dc->sSmall) HIP_TRY (hipStreamSynchronize (dc->sSmall)) ;
             HIP_TRY (hipStreamSynchronize (sCopy)) ;
             HIP_TRY (hipEventElapsedTime (&ms, evStart, evStop)) ;
+            // GPUQR_PROFILE_DUMP=path: one line per launch (round, kernel id, workgroups, microseconds, flops)
+            FILE *dump = (g_profile_on && getenv ("GPUQR_PROFILE_DUMP")) ? fopen (getenv ("GPUQR_PROFILE_DUMP"), "w") : NULL ;
             for (size_t i = 0 ; i < evProfBucket.size ( ) ; i++)
             {
                 float t = 0 ;
                 HIP_TRY (hipEventElapsedTime (&t, evProf [2*i], evProf [2*i+1])) ;
                 const int64_t b = evProfBucket [i] ;
-                KernelProfile &kp = g_profile [b % QR_NKERNELS] ;
+                KernelProfile &kp = g_profile [slot_kernel ((int) (b % QR_NSLOTS))] ;
                 kp.ms += t ; kp.launches++ ; kp.tasks += rptr [b+1] - rptr [b] ;      // workgroups
+                if (dump) fprintf (dump, "%ld %d %ld %.3f %.0f\n", (long) (b / QR_NSLOTS), (int) (b % QR_NSLOTS),
+                    (long) (rptr [b+1] - rptr [b]), t * 1e3, bflops [b]) ;
                 kp.flops += bflops [b] ; kp.bytes += bbytes [b] ;
             }
+            if (dump) fclose (dump) ;
         }
         if (stats)
         {
@@ -935,6 +1038,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
 cleanup:
     if (sCompute) (void) hipStreamSynchronize (sCompute) ;
     if (sApply) (void) hipStreamSynchronize (sApply) ;
+    if (dc && dc->sSmall) (void) hipStreamSynchronize (dc->sSmall) ;
     if (sCopy) (void) hipStreamSynchronize (sCopy) ;
     for (size_t i = 0 ; i < evProf.size ( ) ; i++) (void) hipEventDestroy (evProf [i]) ;
     // streams, events and device buffers stay in the per-device cache for the next call

@@ -104,8 +104,16 @@ def test_subtree_parallel_two_ranks_on_one_gpu(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "tests", "mgpu_worker.py"), "gloo-gpu", out, "20x20"]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=110)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    # own process group, so that a hang can be ended together with the workers it left behind
+    import signal
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        stdout, stderr = proc.communicate(timeout=90)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        stdout, stderr = proc.communicate()
+        raise AssertionError("two-rank run hung:\n" + stdout[-3000:] + stderr[-3000:])
+    assert proc.returncode == 0, stdout[-2000:] + stderr[-2000:]
     z = np.load(out)
     R = sp.csc_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"])).toarray()
     A = problems.stacked_ls((20, 20))
