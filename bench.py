@@ -201,6 +201,15 @@ def main():
             if best is None or ms.value > best[1]:
                 best = (name, ms.value, ln.value, fl.value, by.value)
         name, ms, ln, fl, by = best
+        # HBM bytes per launch from the hardware counters: collected with rocprofv3 --pmc in separate
+        # passes of this same command (a profiler cannot run inside the timed process) and committed
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
+            if args.workload == "dense" and args.copies == COPIES and name in pmc["kernels"]:
+                traffic = pmc["kernels"][name]["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         avg_s = ms / 1e3 / ln
         tflops = fl / ln / avg_s / 1e12
         gbs = by / ln / avg_s / 1e9
@@ -208,7 +217,10 @@ def main():
         # chip's FP64 ridge (78.6 TF / 8 TB/s = 9.8): HBM bounds it
         if name.startswith("k_apply") or name.startswith("k_assemble"):
             roofline = {"kernel": name, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": gbs / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6,
+                        "frac": gbs / PEAK_HBM_GBS, "traffic": traffic,
+                        "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
+                        if traffic is not None else None,
+                        "avg_launch_us": avg_s * 1e6,
                         "launches": ln, "algorithmic_bytes_per_launch": by / ln,
                         "mfma_tflops": tflops, "mfma_frac": tflops / PEAK_FP64_MFMA_TFLOPS}
         else:

@@ -541,8 +541,19 @@ static hipError_t pull_rows (const gpuqr_front &fr, int64_t nrows, hipStream_t s
         (size_t) fr.fn * sizeof (double), (size_t) nrows, hipMemcpyDeviceToHost, stream) ;
 }
 
+#include <chrono>
+static double eng_now_ms (void)
+{
+    return std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now ( ).time_since_epoch ( )).count ( ) ;
+}
+// GPUQR_VERBOSE=2 prints where the host time of an engine call goes
+#define ENG_TICK(label) do { if (eng_verbose) { double t_ = eng_now_ms ( ) ; fprintf (stderr, "    [engine] %-24s %9.2f ms\n", label, t_ - eng_tlast) ; eng_tlast = t_ ; } } while (0)
+
 static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
 {
+    const char *eng_env = getenv ("GPUQR_VERBOSE") ;
+    const bool eng_verbose = eng_env && atoi (eng_env) >= 2 ;
+    double eng_tlast = eng_now_ms ( ) ;
     int code = GPUQR_SUCCESS ;
     QrTask *d_tasks = NULL ;
     QrRef *d_refs = NULL ;
@@ -595,6 +606,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
             if ((int64_t) order.size ( ) != nf) return GPUQR_GPUERROR ;     // cycle in pids
         }
 
+        ENG_TICK ("validate + order") ;
         // ---- build the schedule -----------------------------------------------------
         Plan plan ;
         // per front: latest round of each class that assembled into it; latest round of each class it used
@@ -672,6 +684,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
             }
         }
 
+        ENG_TICK ("plan") ;
         const int64_t ntasks = (int64_t) plan.tasks.size ( ) ;
         int32_t nrounds = 0 ;
         for (int64_t i = 0 ; i < ntasks ; i++) nrounds = std::max (nrounds, plan.tasks [i].round + 1) ;
@@ -721,6 +734,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                 100*wgK[2]/wg, 100*wgK[3]/wg, 100*wgodd/wg, 100*wgmis/wg, 100*wgseg/wg, colsum/wg, nrounds) ;
         }
 
+        ENG_TICK ("bucket sort") ;
         dc = device_cache ( ) ;
         if (!dc) { code = GPUQR_GPUERROR ; goto cleanup ; }
         sCompute = dc->sCompute ; sApply = dc->sApply ; sCopy = dc->sCopy ; evStart = dc->evStart ; evStop = dc->evStop ;
@@ -886,6 +900,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                     for (int32_t b = 0 ; b < st.nblk ; b++) { h_refs [q].task = (int32_t) i ; h_refs [q].blk = b ; q++ ; }
                 }
             }
+            ENG_TICK ("task + ref staging") ;
             HIP_TRY (hipMemcpyAsync (d_tasks, h_tasks, task_bytes, hipMemcpyHostToDevice, sCompute)) ;
             HIP_TRY (hipMemcpyAsync (d_refs, h_refs, ref_bytes, hipMemcpyHostToDevice, sCompute)) ;
 
@@ -1003,11 +1018,13 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
             for (int c = 1 ; c < QR_NCLASS ; c++)
                 if (nrounds > 0 && evAt [c][nrounds-1]) HIP_TRY (hipStreamWaitEvent (sCompute, evAt [c][nrounds-1], 0)) ;
             HIP_TRY (hipEventRecord (evStop, sCompute)) ;
+            ENG_TICK ("launch loop (host)") ;
             HIP_TRY (hipStreamSynchronize (sCompute)) ;
             HIP_TRY (hipStreamSynchronize (sApply)) ;
             if (dc->sSmall) HIP_TRY (hipStreamSynchronize (dc->sSmall)) ;
             HIP_TRY (hipStreamSynchronize (sCopy)) ;
             HIP_TRY (hipEventElapsedTime (&ms, evStart, evStop)) ;
+            ENG_TICK ("wait for the device") ;
             // GPUQR_PROFILE_DUMP=path: one line per launch (round, kernel id, workgroups, microseconds, flops)
             FILE *dump = (g_profile_on && getenv ("GPUQR_PROFILE_DUMP")) ? fopen (getenv ("GPUQR_PROFILE_DUMP"), "w") : NULL ;
             for (size_t i = 0 ; i < evProfBucket.size ( ) ; i++)
