@@ -596,6 +596,34 @@ __device__ void packassemble (const QrPackAssembleTask &t, char *smem)
 }
 
 // -----------------------------------------------------------------------------
+// S entries from the pattern and this factorization's values
+// -----------------------------------------------------------------------------
+//
+// S [k] = (findex [k], Ax [aperm [k]]): where an entry of A lands in its front is known from the
+// symbolic analysis; only the values change between factorizations, so only Ax crosses PCIe.
+
+__global__ void __launch_bounds__ (QR_THREADS) k_build_s (long long *S, const long long *findex, const long long *aperm,
+    const double *Ax, long long count)
+{
+    const long long k = (long long) blockIdx.x * QR_THREADS + threadIdx.x ;
+    if (k < count)
+    {
+        S [2*k] = findex [k] ;
+        S [2*k + 1] = __double_as_longlong (Ax [aperm [k]]) ;
+    }
+}
+
+extern "C" hipError_t qr_launch_build_s (void *d_S, const long long *d_findex, const long long *d_aperm,
+    const double *d_Ax, long long count, hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess ;
+    const long long nb = (count + QR_THREADS - 1) / QR_THREADS ;
+    if (nb > 0x7fffffffLL) return hipErrorInvalidValue ;
+    hipLaunchKernelGGL (k_build_s, dim3 ((unsigned) nb), dim3 (QR_THREADS), 0, stream, (long long *) d_S, d_findex, d_aperm, d_Ax, count) ;
+    return hipGetLastError ( ) ;
+}
+
+// -----------------------------------------------------------------------------
 // R hand-off
 // -----------------------------------------------------------------------------
 //

@@ -225,6 +225,80 @@ struct QrPackRTask ;
 extern "C" hipError_t qr_launch_pack_r (const QrPackRTask *d_tasks, const long long *d_tile_prefix, int nfronts,
     long long ntiles, hipStream_t stream) ;
 struct PackRTask { const double *F ; double *out ; int32_t ld, fn, frank, pad ; } ;     // = QrPackRTask (qr_tasks.h)
+extern "C" hipError_t qr_launch_build_s (void *d_S, const long long *d_findex, const long long *d_aperm,
+    const double *d_Ax, long long count, hipStream_t stream) ;
+
+static void release_numeric_cache (spqr_amd_symbolic::NumericCache *c)
+{
+    if (c->d_Rimap) (void) hipFree (c->d_Rimap) ;
+    if (c->d_Rjmap) (void) hipFree (c->d_Rjmap) ;
+    if (c->d_findex) (void) hipFree (c->d_findex) ;
+    if (c->d_aperm) (void) hipFree (c->d_aperm) ;
+    c->d_Rimap = c->d_Rjmap = c->d_findex = c->d_aperm = NULL ;
+    c->built = false ;
+}
+
+// Maps, staircases and the destination / source of every S entry: pattern only, so done once per
+// symbolic object and device.  Runs the restated spqrgpu_buildAssemblyMaps with the position of
+// each entry in place of its value, which gives the permutation from the caller's Ax to packed S.
+// Returns 0, 1 (out of memory) or 2 (device error).
+static int build_numeric_cache (const spqr_amd_symbolic *S, const int64_t *Ap, const int64_t *Ai)
+{
+    spqr_amd_symbolic::NumericCache &C = S->cache ;
+    int dev = -1 ;
+    if (hipGetDevice (&dev) != hipSuccess) return 2 ;
+    if (C.built && C.device == dev) return 0 ;
+    if (C.built) release_numeric_cache (&C) ;
+    C.release = release_numeric_cache ;
+    const Long nf = S->nf, n = S->n, m = S->m, anz = S->anz ;
+    const Long *Sp = S->Sp.data ( ), *Super = S->Super.data ( ), *Sleft = S->Sleft.data ( ), *Post = S->Post.data ( ) ;
+    // position in Ax of every entry of S = A(P,Q) in row form (spqr_stranspose2's scatter)
+    std::vector<Long> sxperm ((size_t) std::max ((Long) 1, anz)) ;
+    std::vector<double> Sx ((size_t) std::max ((Long) 1, anz)) ;
+    {
+        std::vector<Long> w (Sp, Sp + m) ;
+        for (Long k = 0 ; k < n ; k++)
+        {
+            const Long col = S->Qfill [k] ;
+            for (Long p = Ap [col] ; p < Ap [col+1] ; p++) sxperm [w [S->PLinv [Ai [p]]]++] = p ;
+        }
+        for (Long q = 0 ; q < anz ; q++) Sx [q] = (double) q ;      // exact below 2^53
+    }
+    const Long RimapSize = std::max ((Long) 1, S->RimapSize), RjmapSize = std::max ((Long) 1, S->RjmapSize) ;
+    C.Stair.assign ((size_t) std::max ((Long) 1, S->Rp [nf]), 0) ;
+    C.Rimap.assign ((size_t) RimapSize, 0) ; C.Rjmap.assign ((size_t) RjmapSize, 0) ;
+    std::vector<Long> Fmap ((size_t) std::max ((Long) 1, n)) ;
+    std::vector<gpuqr_sentry> allS ((size_t) std::max ((Long) 1, anz)) ;
+    spqrgpu_amd_build_assembly_maps (nf, n, Fmap.data ( ), Post, Super, S->Rp.data ( ), S->Rj.data ( ), Sleft, Sp,
+        S->Sj.data ( ), Sx.data ( ), S->Fm.data ( ), S->Cm.data ( ), S->Childp.data ( ), S->Child.data ( ), C.Stair.data ( ),
+        C.Rjmap.data ( ), S->RjmapOffsets.data ( ), C.Rimap.data ( ), S->RimapOffsets.data ( ), allS.data ( )) ;
+    std::vector<Long> findex ((size_t) std::max ((Long) 1, anz)), aperm ((size_t) std::max ((Long) 1, anz)) ;
+    for (Long k = 0 ; k < anz ; k++) { findex [k] = allS [k].findex ; aperm [k] = sxperm [(Long) allS [k].value] ; }
+    C.SGlob.assign ((size_t) nf + 1, 0) ;
+    {
+        Long sacc = 0 ;
+        for (Long k = 0 ; k < nf ; k++)
+        {
+            const Long f = Post [k] ;
+            C.SGlob [f] = sacc ;
+            sacc += std::max ((Long) 0, Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]]) ;
+        }
+        C.SGlob [nf] = sacc ;
+    }
+    const size_t nz = (size_t) std::max ((Long) 1, anz) ;
+    if (hipMalloc (&C.d_Rimap, (size_t) RimapSize * sizeof (int32_t)) != hipSuccess) { C.d_Rimap = NULL ; release_numeric_cache (&C) ; return 1 ; }
+    if (hipMalloc (&C.d_Rjmap, (size_t) RjmapSize * sizeof (int32_t)) != hipSuccess) { C.d_Rjmap = NULL ; release_numeric_cache (&C) ; return 1 ; }
+    if (hipMalloc (&C.d_findex, nz * sizeof (Long)) != hipSuccess) { C.d_findex = NULL ; release_numeric_cache (&C) ; return 1 ; }
+    if (hipMalloc (&C.d_aperm, nz * sizeof (Long)) != hipSuccess) { C.d_aperm = NULL ; release_numeric_cache (&C) ; return 1 ; }
+    if (hipMemcpy (C.d_Rimap, C.Rimap.data ( ), (size_t) RimapSize * sizeof (int32_t), hipMemcpyHostToDevice) != hipSuccess
+     || hipMemcpy (C.d_Rjmap, C.Rjmap.data ( ), (size_t) RjmapSize * sizeof (int32_t), hipMemcpyHostToDevice) != hipSuccess
+     || hipMemcpy (C.d_findex, findex.data ( ), nz * sizeof (Long), hipMemcpyHostToDevice) != hipSuccess
+     || hipMemcpy (C.d_aperm, aperm.data ( ), nz * sizeof (Long), hipMemcpyHostToDevice) != hipSuccess)
+        { release_numeric_cache (&C) ; return 2 ; }
+    C.device = dev ;
+    C.built = true ;
+    return 0 ;
+}
 
 extern "C" void spqr_amd_numeric_free (spqr_amd_numeric *num)
 {
@@ -280,7 +354,7 @@ static int factorize_impl
     int code = 0 ;
     const bool verbose = getenv ("GPUQR_VERBOSE") != NULL ;
     double tlast = now_ms ( ) ;
-    const Long nf = S->nf, n = S->n, m = S->m ;
+    const Long nf = S->nf, n = S->n ;
     const Long *Super = S->Super.data ( ), *Rp = S->Rp.data ( ), *Post = S->Post.data ( ) ;
     const Long *Parent = S->Parent.data ( ), *Childp = S->Childp.data ( ), *Child = S->Child.data ( ) ;
     const Long *Fm = S->Fm.data ( ), *Cm = S->Cm.data ( ), *Sleft = S->Sleft.data ( ), *Sp = S->Sp.data ( ) ;
@@ -288,8 +362,7 @@ static int factorize_impl
 
     spqr_amd_numeric *num = (spqr_amd_numeric *) calloc (1, sizeof (spqr_amd_numeric)) ;
     if (!num) return 1 ;
-    Buf dF, dS, dR, dRimap, dRjmap, dTasks, dPrefix, hS, hStage ;
-    hS.pinned = true ; hStage.pinned = true ;
+    Buf dF, dS, dR, dAx, dTasks, dPrefix ;
     std::vector<gpuqr_front> fronts ;
     std::vector<double *> limbo ;
 
@@ -324,38 +397,18 @@ static int factorize_impl
             for (Long f = 0 ; f < nf ; f++) num->Cblock [f] = -1 ;
         }
 
-        // ---- Sx: values of S in row order (spqr_stranspose2) ------------------------------
-        std::vector<double> Sx ((size_t) S->anz) ;
+        TICK ("allocation") ;
+        // ---- maps, staircases, S pattern: once per symbolic object; this call's values of A ------
         {
-            std::vector<Long> w (Sp, Sp + m) ;
-            for (Long k = 0 ; k < n ; k++)
-            {
-                const Long col = S->Qfill [k] ;
-                for (Long p = Ap [col] ; p < Ap [col+1] ; p++) Sx [w [S->PLinv [Ai [p]]]++] = Ax [p] ;
-            }
+            const int cc = build_numeric_cache (S, Ap, Ai) ;
+            if (cc != 0) { code = cc ; goto done ; }
         }
-        TICK ("alloc + Sx") ;
-
-        // ---- maps and packed S for the whole problem ---------------------------------------
-        const Long RimapSize = std::max ((Long) 1, S->RimapSize), RjmapSize = std::max ((Long) 1, S->RjmapSize) ;
-        std::vector<Long> Stair ((size_t) std::max ((Long) 1, Rp [nf])), Fmap ((size_t) std::max ((Long) 1, n)) ;
-        std::vector<int32_t> Rimap ((size_t) RimapSize), Rjmap ((size_t) RjmapSize) ;
-        if (hS.ensure ((size_t) std::max ((Long) 1, S->anz) * sizeof (gpuqr_sentry)) != hipSuccess) { code = 1 ; goto done ; }
-        gpuqr_sentry *allS = (gpuqr_sentry *) hS.p ;
-        spqrgpu_amd_build_assembly_maps (nf, n, Fmap.data ( ), Post, Super, Rp, S->Rj.data ( ), Sleft, Sp,
-            S->Sj.data ( ), Sx.data ( ), Fm, Cm, Childp, Child, Stair.data ( ), Rjmap.data ( ),
-            S->RjmapOffsets.data ( ), Rimap.data ( ), S->RimapOffsets.data ( ), allS) ;
-        // packed S is laid out front after front in postorder
-        std::vector<Long> SGlob ((size_t) nf + 1, 0) ;
-        {
-            Long sacc = 0 ;
-            for (Long k = 0 ; k < nf ; k++) { SGlob [Post [k]] = sacc ; sacc += S_count (Post [k]) ; }
-        }
-        if (dRimap.ensure ((size_t) RimapSize * sizeof (int32_t)) != hipSuccess) { code = 1 ; goto done ; }
-        if (dRjmap.ensure ((size_t) RjmapSize * sizeof (int32_t)) != hipSuccess) { code = 1 ; goto done ; }
-        HIPCHK (hipMemcpy (dRimap.p, Rimap.data ( ), (size_t) RimapSize * sizeof (int32_t), hipMemcpyHostToDevice)) ;
-        HIPCHK (hipMemcpy (dRjmap.p, Rjmap.data ( ), (size_t) RjmapSize * sizeof (int32_t), hipMemcpyHostToDevice)) ;
-        TICK ("assembly maps + upload") ;
+        const spqr_amd_symbolic::NumericCache &NC = S->cache ;
+        const std::vector<Long> &Stair = NC.Stair ;
+        const std::vector<Long> &SGlob = NC.SGlob ;
+        TICK ("maps + S pattern (cached)") ;
+        if (dAx.ensure ((size_t) std::max ((Long) 1, S->anz) * sizeof (double)) != hipSuccess) { code = 1 ; goto done ; }
+        if (S->anz > 0) HIPCHK (hipMemcpyAsync (dAx.p, Ax, (size_t) S->anz * sizeof (double), hipMemcpyHostToDevice, 0)) ;
 
         limbo.assign ((size_t) std::max ((Long) 1, nf), (double *) NULL) ;
         std::vector<Long> rel ((size_t) std::max ((Long) 1, nf), -1), pitch ((size_t) std::max ((Long) 1, nf), 0) ;
@@ -406,13 +459,15 @@ static int factorize_impl
             TICK ("workspace allocation") ;
 
             HIPCHK (hipMemsetAsync (F0, 0, (size_t) std::max ((Long) 1, fsum) * sizeof (double), 0)) ;
-            // S entries of the group: runs of fronts that are neighbours in postorder go in one copy
+            // S entries of the group, built on the device; runs of fronts that are neighbours in
+            // postorder go in one launch
             for (Long k = 0 ; k < numFronts ; )
             {
                 Long k2 = k, cnt = 0 ;
                 while (k2 < numFronts && SGlob [list [k2]] == SGlob [list [k]] + cnt) { cnt += S_count (list [k2]) ; k2++ ; }
                 if (cnt > 0)
-                    HIPCHK (hipMemcpyAsync (S0 + SOff [k], allS + SGlob [list [k]], (size_t) cnt * sizeof (gpuqr_sentry), hipMemcpyHostToDevice, 0)) ;
+                    HIPCHK (qr_launch_build_s (S0 + SOff [k], (const long long *) NC.d_findex + SGlob [list [k]],
+                        (const long long *) NC.d_aperm + SGlob [list [k]], (const double *) dAx.p, cnt, 0)) ;
                 k = k2 ;
             }
 
@@ -430,7 +485,7 @@ static int factorize_impl
                 fr.fids = k ; fr.pids = parent_here ? rel [pid] : -1 ; fr.fidg = f ; fr.pidg = pid ;
                 fr.fm = fm ; fr.fn = fn ; fr.fp = fp ; fr.rank = frank ;
                 fr.ldn = pitch [f] ;
-                fr.Stair = Stair.data ( ) + Rp [f] ;
+                fr.Stair = (int64_t *) Stair.data ( ) + Rp [f] ;
                 fr.gpuF = F0 + FOff [k] ;
                 fr.cpuR = NULL ;                    // R is packed on the device, see below
                 fr.is_sparse = 1 ;
@@ -442,8 +497,8 @@ static int factorize_impl
                 if (parent_here)
                 {
                     fr.pn = (int32_t) pitch [pid] ;
-                    fr.gpuRjmap = (int32_t *) dRjmap.p + S->RjmapOffsets [f] ;
-                    fr.gpuRimap = (int32_t *) dRimap.p + S->RimapOffsets [f] ;
+                    fr.gpuRjmap = (int32_t *) NC.d_Rjmap + S->RjmapOffsets [f] ;
+                    fr.gpuRimap = (int32_t *) NC.d_Rimap + S->RimapOffsets [f] ;
                     fr.gpuC = fr.gpuF + frank * pitch [f] + fp ;
                 }
                 else if (pid < nf)
@@ -465,8 +520,8 @@ static int factorize_impl
                     ch.fm = ccm ; ch.fn = ccn ; ch.fp = 0 ; ch.rank = 0 ; ch.ldn = ccn ;
                     ch.is_sparse = 1 ; ch.push_only = 1 ;
                     ch.pn = (int32_t) pitch [f] ; ch.cm = (int32_t) ccm ; ch.cn = (int32_t) ccn ;
-                    ch.gpuRimap = (int32_t *) dRimap.p + S->RimapOffsets [c] ;
-                    ch.gpuRjmap = (int32_t *) dRjmap.p + S->RjmapOffsets [c] ;
+                    ch.gpuRimap = (int32_t *) NC.d_Rimap + S->RimapOffsets [c] ;
+                    ch.gpuRjmap = (int32_t *) NC.d_Rjmap + S->RjmapOffsets [c] ;
                     ch.gpuF = ch.gpuC = F0 + child_off ;
                     if (ccm * ccn > 0)
                     {
