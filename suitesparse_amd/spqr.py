@@ -187,3 +187,30 @@ def s_values(sym, A):
             Sx[w[r]] = A.data[p]
             w[r] += 1
     return Sx
+
+
+def qr_solve(A, B, Q=None, relax=0, gpuMemorySize=2**34):
+    """min ||A x - B||_2 the way SuiteSparseQR gets Q'B on the GPU path (SuiteSparseQR.cpp:256-260):
+    B's columns are appended to A and ride through the same factorization, so that the first n rows
+    of their part of R are C = Q'B; the back substitution R x = C is done on the host, as
+    spqr_rsolve is in the reference.  A is m-by-n of full column rank, B m-by-k dense.
+    Returns (x in A's column order, R, Symbolic of [A B])."""
+    from scipy.sparse.linalg import spsolve_triangular
+    A = sp.csc_matrix(A)
+    m, n = A.shape
+    B = np.asarray(B, dtype=np.float64).reshape(m, -1)
+    k = B.shape[1]
+    AB = sp.hstack([A, sp.csc_matrix(B)], format="csc")
+    Qa = np.arange(n) if Q is None else np.asarray(Q)
+    Qab = np.concatenate([Qa, n + np.arange(k)])          # B's columns stay last, as in SPQR
+    sym = analyze(AB, Qab, relax=relax, gpuMemorySize=gpuMemorySize)
+    res = factorize(sym, AB)
+    R = res.R.tocsc()
+    if res.rank < n:
+        raise np.linalg.LinAlgError("A(:,Q) is structurally rank deficient on the GPU path (rank %d < %d)" % (res.rank, n))
+    R11 = R[:n, :n].tocsr()
+    Cq = R[:n, n:].toarray()
+    y = spsolve_triangular(R11, Cq, lower=False)
+    x = np.zeros((n, k))
+    x[sym.Qfill[:n]] = y                                   # R is the factor of A(:,Qfill)
+    return x, R, sym

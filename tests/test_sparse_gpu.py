@@ -120,3 +120,18 @@ def test_subtree_parallel_two_ranks_on_one_gpu(tmp_path):
     Rl = np.linalg.qr(A[:, z["Qfill"]].toarray(), mode="r")
     assert int(z["n_cut"]) >= 2
     assert r_rel_diff(rownorm_sign(R), rownorm_sign(Rl)) <= 1e-12
+
+
+@pytest.mark.parametrize("grid,leaf", [((24, 24), 4), ((8, 8, 8), 2)])
+def test_least_squares_through_appended_rhs(grid, leaf):
+    """x = R \\ (Q'b) with Q'b obtained by appending b to A (SuiteSparseQR.cpp:256-260), checked
+    against the dense least-squares solution and the normal-equations residual of qrdemo_gpu.cpp:92-113."""
+    A = problems.stacked_ls(grid)
+    m, n = A.shape
+    rng = np.random.default_rng(12)
+    B = np.column_stack([np.ones(m), rng.standard_normal(m)])
+    x, R, sym = spqr.qr_solve(A, B, problems.nested_dissection(grid, leaf=leaf), relax=20)
+    xref = np.linalg.lstsq(A.toarray(), B, rcond=None)[0]
+    assert np.abs(x - xref).max() <= 1e-11 * np.abs(xref).max()
+    r = A @ x - B
+    assert np.abs(A.T @ r).max() <= 1e-11 * np.abs(A).max() * np.abs(B).max() * m ** 0.5
