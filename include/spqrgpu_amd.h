@@ -88,7 +88,8 @@ typedef struct spqr_amd_numeric
 {
     int64_t  nf;
     int64_t  rsize;         /* doubles in Rstack */
-    double  *Rstack;        /* all R blocks, column-packed upper trapezoidal, as on SPQR's stack */
+    double  *Rstack;        /* all R blocks, column-packed upper trapezoidal, as on SPQR's stack; pinned
+                               host memory owned by the object: release with spqr_amd_numeric_free only */
     int64_t *Rblock;        /* size nf: offset of front f's block in Rstack */
     char    *Rdead;         /* size n: 1 for pivot columns past the bottom of their front */
     int64_t  sumfrank, maxfrank;
@@ -109,6 +110,11 @@ int spqrgpu_amd_factorize (const spqr_amd_symbolic *sym, const int64_t *Ap, cons
                            const double *Ax, spqr_amd_numeric **num_out);
 
 void spqr_amd_numeric_free (spqr_amd_numeric *num);
+
+/* The numeric driver keeps its device workspaces (front arena, S, packed R) per device between
+ * calls, grow-only, as the reference keeps its Workspace objects alive across stages
+ * (SPQR/SPQRGPU/spqrgpu_kernel.cpp:221-330 allocates them once per factorization).  This frees them. */
+void spqrgpu_amd_finalize (void);
 
 /* R as an n-column compressed-column matrix (rows = sumfrank), the job of
  * spqr_rcount + spqr_rconvert (SPQR/Source/spqr_rconvert.cpp).  First call

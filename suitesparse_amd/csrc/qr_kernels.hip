@@ -355,6 +355,13 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
 
 #define VS_LD 34
 
+#ifdef ABL_NOMFMA
+// timing-only build: the matrix instructions are replaced by one add that keeps the operands alive
+#define MFMA64(a, b, c) ((c) + (v4f64) {(a) * (b), 0.0, 0.0, 0.0})
+#else
+#define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64 ((a), (b), (c), 0, 0, 0)
+#endif
+
 typedef double d2 __attribute__((ext_vector_type(2))) ;
 typedef __attribute__((address_space(1))) d2 __attribute__((aligned(8))) gd2 ;  // rows of odd fn are only 8-byte aligned
 
@@ -481,8 +488,8 @@ __device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk
                 {
                     const int r = mt*16 + 8*h + 2*lr + e ;
                     const double b = A [mt][h][e] ;
-                    W0 = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [r][lc],      b, W0, 0, 0, 0) ;
-                    W1 = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [r][16 + lc], b, W1, 0, 0, 0) ;
+                    W0 = MFMA64 (Vs [r][lc],      b, W0) ;
+                    W1 = MFMA64 (Vs [r][16 + lc], b, W1) ;
                 }
             }
         }
@@ -492,13 +499,13 @@ __device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk
         #pragma unroll
         for (int q = 0 ; q < 4 ; q++)
         {
-            X0 = __builtin_amdgcn_mfma_f64_16x16x4f64 (Ts [4*q + lr][lc],      W0 [q], X0, 0, 0, 0) ;
-            X1 = __builtin_amdgcn_mfma_f64_16x16x4f64 (Ts [4*q + lr][16 + lc], W0 [q], X1, 0, 0, 0) ;
+            X0 = MFMA64 (Ts [4*q + lr][lc],      W0 [q], X0) ;
+            X1 = MFMA64 (Ts [4*q + lr][16 + lc], W0 [q], X1) ;
         }
         #pragma unroll
         for (int q = 0 ; q < 4 ; q++)
         {
-            X1 = __builtin_amdgcn_mfma_f64_16x16x4f64 (Ts [16 + 4*q + lr][16 + lc], W1 [q], X1, 0, 0, 0) ;
+            X1 = MFMA64 (Ts [16 + 4*q + lr][16 + lc], W1 [q], X1) ;
         }
         X0 = -X0 ; X1 = -X1 ;
 
@@ -514,10 +521,10 @@ __device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk
             v4f64 acc = {A [mt][0][0], A [mt][0][1], A [mt][1][0], A [mt][1][1]} ;
             #pragma unroll
             for (int q = 0 ; q < 4 ; q++)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [mt*16 + pi_lc][4*q + lr], X0 [q], acc, 0, 0, 0) ;
+                acc = MFMA64 (Vs [mt*16 + pi_lc][4*q + lr], X0 [q], acc) ;
             #pragma unroll
             for (int q = 0 ; q < 4 ; q++)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (Vs [mt*16 + pi_lc][16 + 4*q + lr], X1 [q], acc, 0, 0, 0) ;
+                acc = MFMA64 (Vs [mt*16 + pi_lc][16 + 4*q + lr], X1 [q], acc) ;
             #pragma unroll
             for (int h = 0 ; h < 2 ; h++)
             {

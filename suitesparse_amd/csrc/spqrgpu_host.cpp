@@ -326,6 +326,25 @@ struct Buf
     ~Buf ( ) { release ( ) ; }
 } ;
 
+struct Workspaces { Buf dF, dS, dR, dAx, dTasks, dPrefix ; } ;
+#define MAX_WS_DEVICES 64
+static Workspaces g_ws [MAX_WS_DEVICES] ;
+
+// Frees the cached device workspaces of every device (they are grow-only between calls).
+extern "C" void spqrgpu_amd_finalize (void)
+{
+    int cur = -1 ;
+    (void) hipGetDevice (&cur) ;
+    for (int d = 0 ; d < MAX_WS_DEVICES ; d++)
+    {
+        Workspaces &W = g_ws [d] ;
+        if (!W.dF.p && !W.dS.p && !W.dR.p && !W.dAx.p && !W.dTasks.p && !W.dPrefix.p) continue ;
+        if (hipSetDevice (d) != hipSuccess) continue ;
+        W.dF.release ( ) ; W.dS.release ( ) ; W.dR.release ( ) ; W.dAx.release ( ) ; W.dTasks.release ( ) ; W.dPrefix.release ( ) ;
+    }
+    if (cur >= 0) (void) hipSetDevice (cur) ;
+}
+
 // The numeric factorization of a set of fronts, group by group.  Mirrors
 // spqrgpu_kernel.cpp:63-782: build S and the maps, then per group (a stage of
 // the staging, or one process's share of the tree) zero the front arena, ship
@@ -362,7 +381,12 @@ static int factorize_impl
 
     spqr_amd_numeric *num = (spqr_amd_numeric *) calloc (1, sizeof (spqr_amd_numeric)) ;
     if (!num) return 1 ;
-    Buf dF, dS, dR, dAx, dTasks, dPrefix ;
+    // device workspaces live in a per-device cache between calls: allocating and freeing tens of
+    // gigabytes costs seconds (5-6 s per call at 96^3), far more than anything else on the host side
+    int wdev = 0 ;
+    if (hipGetDevice (&wdev) != hipSuccess || wdev < 0 || wdev >= MAX_WS_DEVICES) { free (num) ; return 2 ; }
+    Workspaces &WS = g_ws [wdev] ;
+    Buf &dF = WS.dF, &dS = WS.dS, &dR = WS.dR, &dAx = WS.dAx, &dTasks = WS.dTasks, &dPrefix = WS.dPrefix ;
     std::vector<gpuqr_front> fronts ;
     std::vector<double *> limbo ;
 
