@@ -99,6 +99,7 @@ typedef struct spqr_amd_numeric
     double   assembleBytes; /* algorithmic bytes moved by S- and pack-assembly */
     double  *Cstack;        /* subset driver: contribution blocks leaving this process (compact cm-by-cn) */
     int64_t *Cblock;        /* subset driver: size nf, offset of front f's block in Cstack or -1 */
+    int64_t  RstackPinned;  /* 1: Rstack is pinned host memory; 0: the pinned allocation was refused and it is pageable */
 } spqr_amd_numeric;
 
 /* Replaces void spqrgpu_kernel (spqr_blob <double> *Blob)

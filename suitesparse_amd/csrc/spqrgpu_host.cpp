@@ -188,7 +188,7 @@ extern "C" void spqrgpu_amd_build_assembly_maps
 #include <atomic>
 
 // Run body(k) for k in [0,n) on a few host threads (dynamic, one index at a time).
-template <class Body> static void parallel_for (Long n, Body body)
+template <class Body> static void parallel_for (Long n, Body body, Long serial_below = 64)
 {
     unsigned hw = std::thread::hardware_concurrency ( ) ;
     const char *env = getenv ("OMP_NUM_THREADS") ;
@@ -196,11 +196,12 @@ template <class Body> static void parallel_for (Long n, Body body)
     if (want < 1) want = 1 ;
     unsigned nt = (unsigned) std::min<long> (want, hw ? hw : 1) ;
     if (nt > 16) nt = 16 ;
-    if (n < 64 || nt <= 1) { for (Long k = 0 ; k < n ; k++) body (k) ; return ; }
+    if (n < serial_below || n < 2 || nt <= 1) { for (Long k = 0 ; k < n ; k++) body (k) ; return ; }
     std::atomic<Long> next (0) ;
     std::vector<std::thread> pool ;
-    auto work = [&] ( ) { for (Long k = next.fetch_add (16) ; k < n ; k = next.fetch_add (16))
-        for (Long q = k ; q < std::min (k + 16, n) ; q++) body (q) ; } ;
+    const Long grain = (n >= 1024) ? 16 : 1 ;
+    auto work = [&] ( ) { for (Long k = next.fetch_add (grain) ; k < n ; k = next.fetch_add (grain))
+        for (Long q = k ; q < std::min (k + grain, n) ; q++) body (q) ; } ;
     for (unsigned t = 1 ; t < nt ; t++) pool.emplace_back (work) ;
     work ( ) ;
     for (size_t t = 0 ; t < pool.size ( ) ; t++) pool [t].join ( ) ;
@@ -303,7 +304,7 @@ static int build_numeric_cache (const spqr_amd_symbolic *S, const int64_t *Ap, c
 extern "C" void spqr_amd_numeric_free (spqr_amd_numeric *num)
 {
     if (!num) return ;
-    if (num->Rstack) (void) hipHostFree (num->Rstack) ;      // pinned: the packed R arrives by DMA
+    if (num->Rstack) { if (num->RstackPinned) (void) hipHostFree (num->Rstack) ; else free (num->Rstack) ; }
     free (num->Rblock) ; free (num->Rdead) ; free (num->Cstack) ; free (num->Cblock) ;
     free (num) ;
 }
@@ -326,7 +327,48 @@ struct Buf
     ~Buf ( ) { release ( ) ; }
 } ;
 
-struct Workspaces { Buf dF, dS, dR, dAx, dTasks, dPrefix ; } ;
+struct Workspaces { Buf dF, dS, dR, dAx, dTasks, dPrefix, hBounce [2] ; } ;
+
+// Device -> pageable host memory through two pinned bounce buffers: the DMA of one piece overlaps
+// the host threads copying the previous piece out (a direct copy into pageable memory ran at
+// 2.5 GB/s for the 87 GB of R of the 128^3 problem).
+static hipError_t copy_to_pageable (void *dst, const void *src_dev, size_t bytes, Buf bounce [2])
+{
+    const size_t piece = (size_t) 256 << 20 ;
+    hipError_t e ;
+    for (int b = 0 ; b < 2 ; b++) { bounce [b].pinned = true ; if ((e = bounce [b].ensure (piece)) != hipSuccess) return e ; }
+    size_t done = 0 ;
+    int cur = 0 ;
+    size_t len_prev = 0 ; char *dst_prev = NULL ; int prev = -1 ;
+    while (done < bytes || prev >= 0)
+    {
+        size_t len = 0 ;
+        if (done < bytes)
+        {
+            len = std::min (piece, bytes - done) ;
+            if ((e = hipMemcpyAsync (bounce [cur].p, (const char *) src_dev + done, len, hipMemcpyDeviceToHost, 0)) != hipSuccess) return e ;
+        }
+        if (prev >= 0)
+        {
+            // the previous piece has landed (its copy was waited for below): spread it over the host threads
+            const size_t nchunk = (len_prev + ((size_t) 4 << 20) - 1) / ((size_t) 4 << 20) ;
+            const char *sp = (const char *) bounce [prev].p ;
+            parallel_for ((Long) nchunk, [&] (Long k)
+            {
+                const size_t o = (size_t) k * ((size_t) 4 << 20) ;
+                memcpy (dst_prev + o, sp + o, std::min ((size_t) 4 << 20, len_prev - o)) ;
+            }, 1) ;
+            prev = -1 ;
+        }
+        if (len > 0)
+        {
+            if ((e = hipStreamSynchronize (0)) != hipSuccess) return e ;
+            prev = cur ; len_prev = len ; dst_prev = (char *) dst + done ;
+            done += len ; cur ^= 1 ;
+        }
+    }
+    return hipSuccess ;
+}
 #define MAX_WS_DEVICES 64
 static Workspaces g_ws [MAX_WS_DEVICES] ;
 
@@ -341,6 +383,7 @@ extern "C" void spqrgpu_amd_finalize (void)
         if (!W.dF.p && !W.dS.p && !W.dR.p && !W.dAx.p && !W.dTasks.p && !W.dPrefix.p) continue ;
         if (hipSetDevice (d) != hipSuccess) continue ;
         W.dF.release ( ) ; W.dS.release ( ) ; W.dR.release ( ) ; W.dAx.release ( ) ; W.dTasks.release ( ) ; W.dPrefix.release ( ) ;
+        W.hBounce [0].release ( ) ; W.hBounce [1].release ( ) ;
     }
     if (cur >= 0) (void) hipSetDevice (cur) ;
 }
@@ -407,8 +450,16 @@ static int factorize_impl
         }
         num->nf = nf ;
         num->rsize = rtotal ;
-        if (hipHostMalloc ((void **) &num->Rstack, (size_t) std::max ((Long) 1, rtotal) * sizeof (double), hipHostMallocDefault) != hipSuccess)
-            { num->Rstack = NULL ; code = 1 ; goto done ; }
+        // pinned, so that the packed R arrives by DMA; pageable if the system refuses that much pinned memory
+        num->RstackPinned = 1 ;
+        if (getenv ("GPUQR_PAGEABLE_R") != NULL       // test knob: take the fallback path
+            || hipHostMalloc ((void **) &num->Rstack, (size_t) std::max ((Long) 1, rtotal) * sizeof (double), hipHostMallocDefault) != hipSuccess)
+        {
+            (void) hipGetLastError ( ) ;
+            num->RstackPinned = 0 ;
+            num->Rstack = (double *) malloc ((size_t) std::max ((Long) 1, rtotal) * sizeof (double)) ;
+            if (!num->Rstack) { code = 1 ; goto done ; }
+        }
         num->Rblock = (Long *) malloc ((size_t) std::max ((Long) 1, nf) * sizeof (Long)) ;
         num->Rdead = (char *) calloc ((size_t) std::max ((Long) 1, n), 1) ;
         if (!num->Rblock || !num->Rdead) { code = 1 ; goto done ; }
@@ -592,8 +643,13 @@ static int factorize_impl
                 HIPCHK (hipMemcpyAsync (dTasks.p, ptasks.data ( ), (size_t) numFronts * sizeof (PackRTask), hipMemcpyHostToDevice, 0)) ;
                 HIPCHK (hipMemcpyAsync (dPrefix.p, prefix.data ( ), (size_t) (numFronts + 1) * sizeof (long long), hipMemcpyHostToDevice, 0)) ;
                 HIPCHK (qr_launch_pack_r ((const QrPackRTask *) dTasks.p, (const long long *) dPrefix.p, (int) numFronts, prefix [numFronts], 0)) ;
-                if (rsum > 0)
+                if (rsum > 0 && num->RstackPinned)
                     HIPCHK (hipMemcpyAsync (num->Rstack + rhead, dR.p, (size_t) rsum * sizeof (double), hipMemcpyDeviceToHost, 0)) ;
+                else if (rsum > 0)
+                {
+                    HIPCHK (hipStreamSynchronize (0)) ;
+                    HIPCHK (copy_to_pageable (num->Rstack + rhead, dR.p, (size_t) rsum * sizeof (double), WS.hBounce)) ;
+                }
                 rhead += rsum ;
 
                 // contribution blocks that leave the group: compact cm-by-cn, zero below the diagonal

@@ -25,7 +25,8 @@ class Numeric(C.Structure):
                 ("sumfrank", C.c_int64), ("maxfrank", C.c_int64), ("gpuKernelTime", C.c_double),
                 ("gpuFlops", C.c_int64), ("gpuNumKernelLaunches", C.c_int64),
                 ("numStagesRun", C.c_int64), ("assembleBytes", C.c_double),
-                ("Cstack", C.POINTER(C.c_double)), ("Cblock", C.POINTER(C.c_int64))]
+                ("Cstack", C.POINTER(C.c_double)), ("Cblock", C.POINTER(C.c_int64)),
+                ("RstackPinned", C.c_int64)]
 
 
 _ARRAYS = ["Qfill", "PLinv", "Sleft", "Sp", "Sj", "Super", "Rp", "Rj", "Parent", "Childp", "Child",

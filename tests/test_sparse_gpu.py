@@ -135,3 +135,15 @@ def test_least_squares_through_appended_rhs(grid, leaf):
     assert np.abs(x - xref).max() <= 1e-11 * np.abs(xref).max()
     r = A @ x - B
     assert np.abs(A.T @ r).max() <= 1e-11 * np.abs(A).max() * np.abs(B).max() * m ** 0.5
+
+
+def test_pageable_r_stack_fallback(monkeypatch):
+    """When the system refuses the pinned R stack the driver copies through bounce buffers into
+    pageable memory: same R."""
+    grid = (30, 30)
+    A = problems.stacked_ls(grid)
+    sym = spqr.analyze(A, problems.nested_dissection(grid, leaf=4), relax=20, gpuMemorySize=2**34)
+    r0 = spqr.factorize(sym, A)
+    monkeypatch.setenv("GPUQR_PAGEABLE_R", "1")
+    r1 = spqr.factorize(sym, A)
+    assert (r0.R != r1.R).nnz == 0
