@@ -431,7 +431,9 @@ static int factorize_impl
     Workspaces &WS = g_ws [wdev] ;
     Buf &dF = WS.dF, &dS = WS.dS, &dR = WS.dR, &dAx = WS.dAx, &dTasks = WS.dTasks, &dPrefix = WS.dPrefix ;
     std::vector<gpuqr_front> fronts ;
-    std::vector<double *> limbo ;
+    std::vector<double *> limbo ;           // contribution blocks waiting on the host for a later stage
+    std::vector<double *> limbo_dev ;       // ... or on the device, when it has the room (no PCIe round trip)
+    std::vector<double *> used_dev ;        // device limbo blocks consumed by the running stage
 
     try
     {
@@ -486,6 +488,7 @@ static int factorize_impl
         if (S->anz > 0) HIPCHK (hipMemcpyAsync (dAx.p, Ax, (size_t) S->anz * sizeof (double), hipMemcpyHostToDevice, 0)) ;
 
         limbo.assign ((size_t) std::max ((Long) 1, nf), (double *) NULL) ;
+        limbo_dev.assign ((size_t) std::max ((Long) 1, nf), (double *) NULL) ;
         std::vector<Long> rel ((size_t) std::max ((Long) 1, nf), -1), pitch ((size_t) std::max ((Long) 1, nf), 0) ;
         for (Long f = 0 ; f < nf ; f++) { const Long fn = Rp [f+1] - Rp [f] ; pitch [f] = fn + (fn & 1) ; }
 
@@ -598,7 +601,14 @@ static int factorize_impl
                     ch.gpuRimap = (int32_t *) NC.d_Rimap + S->RimapOffsets [c] ;
                     ch.gpuRjmap = (int32_t *) NC.d_Rjmap + S->RjmapOffsets [c] ;
                     ch.gpuF = ch.gpuC = F0 + child_off ;
-                    if (ccm * ccn > 0)
+                    if (ccm * ccn > 0 && !mine && limbo_dev [c])
+                    {
+                        // the block never left the device: assemble straight from where it waits
+                        ch.gpuF = ch.gpuC = limbo_dev [c] ;
+                        used_dev.push_back (limbo_dev [c]) ;
+                        limbo_dev [c] = NULL ;
+                    }
+                    else if (ccm * ccn > 0)
                     {
                         const double *src = mine ? (limbo_in ? limbo_in [c] : NULL) : limbo [c] ;
                         if (!src) { code = mine ? 3 : 2 ; goto done ; }
@@ -622,6 +632,8 @@ static int factorize_impl
             num->gpuFlops += stats.flopsActual ;
             num->gpuNumKernelLaunches += stats.numLaunches ;
             num->numStagesRun++ ;
+            for (size_t i = 0 ; i < used_dev.size ( ) ; i++) (void) hipFree (used_dev [i]) ;
+            used_dev.clear ( ) ;
 
             // ---- R: packed on the device, one copy onto the stack ---------------------------------
             {
@@ -662,8 +674,19 @@ static int factorize_impl
                     const Long cn = fn - fp, cm = mine ? Cm [f] : std::min (fm - frank, cn) ;
                     double *L ;
                     if (mine) { L = num->Cstack + chead ; num->Cblock [f] = chead ; chead += Cm [f] * cn ; }
+                    else if (cm > 0 && cn > 0 && getenv ("GPUQR_HOST_LIMBO") == NULL
+                        && hipMalloc ((void **) &limbo_dev [f], (size_t) (cm * cn) * sizeof (double)) == hipSuccess)
+                    {
+                        // room on the device: the block waits there (what lies below its diagonal is
+                        // never read by the assembly, so it is not cleared)
+                        HIPCHK (hipMemcpy2DAsync (limbo_dev [f], (size_t) cn * sizeof (double), fronts [k].gpuF + frank * pitch [f] + fp,
+                            (size_t) pitch [f] * sizeof (double), (size_t) cn * sizeof (double), (size_t) cm, hipMemcpyDeviceToDevice, 0)) ;
+                        continue ;
+                    }
                     else
                     {
+                        (void) hipGetLastError ( ) ;
+                        limbo_dev [f] = NULL ;
                         L = (double *) calloc ((size_t) std::max ((Long) 1, cm * cn), sizeof (double)) ;
                         if (!L) { code = 1 ; goto done ; }
                         limbo [f] = L ;
@@ -709,6 +732,8 @@ static int factorize_impl
 
 done:
     for (size_t i = 0 ; i < limbo.size ( ) ; i++) free (limbo [i]) ;
+    for (size_t i = 0 ; i < limbo_dev.size ( ) ; i++) if (limbo_dev [i]) (void) hipFree (limbo_dev [i]) ;
+    for (size_t i = 0 ; i < used_dev.size ( ) ; i++) (void) hipFree (used_dev [i]) ;
     if (code != 0) { spqr_amd_numeric_free (num) ; return code ; }
     *num_out = num ;
     return 0 ;

@@ -59,10 +59,14 @@ def test_sparse_qr_one_stage(name, A, Q, relax):
 
 @pytest.mark.parametrize("name,A,Q", CASES[:4], ids=[c[0] for c in CASES[:4]])
 @pytest.mark.parametrize("mem", [0, 10_700_000, 11_200_000])
-def test_sparse_qr_staged_equals_one_stage(name, A, Q, mem):
-    """Shrinking the declared device memory forces several stages and the host "limbo" round trip
-    of contribution blocks (the reference tests staging the same way, SPQR/Tcov/qrtest.cpp:2660-2684).
-    The factor must not depend on the staging."""
+@pytest.mark.parametrize("host_limbo", [False, True])
+def test_sparse_qr_staged_equals_one_stage(name, A, Q, mem, host_limbo, monkeypatch):
+    """Shrinking the declared device memory forces several stages and the "limbo" wait of
+    contribution blocks between them (the reference tests staging the same way,
+    SPQR/Tcov/qrtest.cpp:2660-2684): on the host as in the reference, or on the device when it has
+    the room.  The factor must not depend on the staging."""
+    if host_limbo:
+        monkeypatch.setenv("GPUQR_HOST_LIMBO", "1")
     one = spqr.factorize(spqr.analyze(A, Q, gpuMemorySize=2**34), A)
     sym = spqr.analyze(A, Q, gpuMemorySize=mem)
     if sym.status == 2:
