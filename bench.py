@@ -58,6 +58,25 @@ def cpu_baseline_dense():
                       % (len(shapes), fl / 1e9, sec)}
 
 
+def cpu_baseline_sparse(kind, k):
+    """The C oracle's whole-tree multifrontal QR (a port; serial over fronts) on a bounded sample of the
+    same generator: the grid shrunk until the run takes seconds."""
+    import time as _t
+    from oracle import oracle
+    from suitesparse_amd import problems, spqr
+    ks = min(k, 384 if kind == "sparse2d" else 28)
+    shape = (ks, ks) if kind == "sparse2d" else (ks, ks, ks)
+    A = problems.stacked_ls(shape)
+    sym = spqr.analyze(A, problems.nested_dissection(shape, leaf=8), relax=20, gpuMemorySize=200 * 2**30)
+    Sx = spqr.s_values(sym, A)
+    t0 = _t.perf_counter()
+    oracle.multifrontal(sym, Sx)
+    sec = _t.perf_counter() - t0
+    return {"value": sym.flopcount / sec / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "sample": "%s grid %s of the same generator (%.2f GFLOP, %.1f s)"
+                      % (kind, "x".join(map(str, shape)), sym.flopcount / 1e9, sec)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,8 +259,9 @@ def main():
             "pct_fp64_mfma_peak": 100.0 * value / world / 1e3 / PEAK_FP64_MFMA_TFLOPS,
             "roofline": roofline, "per_kernel": per_kernel,
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload == "dense":
-            out["cpu_baseline"] = cpu_baseline_dense()
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = (cpu_baseline_dense() if args.workload == "dense"
+                                   else cpu_baseline_sparse(*[f(x) for f, x in zip((str, int), args.workload.split(":"))]))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
