@@ -689,8 +689,34 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
         int32_t nrounds = 0 ;
         for (int64_t i = 0 ; i < ntasks ; i++) nrounds = std::max (nrounds, plan.tasks [i].round + 1) ;
 
-        // counting sort of the workgroups by (round, launch slot): one launch per non-empty bucket
         const int64_t nbuckets = (int64_t) nrounds * QR_NSLOTS ;
+        // An update launch that cannot fill the chip runs as long as one of its workgroups does:
+        // there the column blocks are made narrower (more, shorter workgroups).  The threshold is in
+        // workgroups per launch; one workgroup slot = half a compute unit.
+        {
+            static int thr = -1 ;
+            if (thr < 0) { const char *e = getenv ("GPUQR_NARROW_BELOW") ; thr = e ? atoi (e) : 128 ; }
+            hvec<int64_t> total ((size_t) nbuckets, 0) ;
+            for (int64_t i = 0 ; i < ntasks ; i++)
+                if (plan.tasks [i].t.type == QR_TASK_APPLY) total [(int64_t) plan.tasks [i].round * QR_NSLOTS + plan.tasks [i].slot] += plan.tasks [i].nblk ;
+            for (int64_t i = 0 ; i < ntasks ; i++)
+            {
+                SchedTask &st = plan.tasks [i] ;
+                if (st.t.type != QR_TASK_APPLY) continue ;
+                QrPanelTask &pt = st.t.u.panel ;
+                int64_t tot = total [(int64_t) st.round * QR_NSLOTS + st.slot] ;
+                const int32_t width = pt.c_end - pt.c_begin ;
+                while (tot < thr && pt.cb_cols > 32 && width > pt.cb_cols / 2)
+                {
+                    pt.cb_cols /= 2 ;
+                    tot *= 2 ;
+                }
+                const int32_t nb = (width + pt.cb_cols - 1) / pt.cb_cols ;
+                st.bytes += (double) (nb - st.nblk) * (8.0 * pt.K * pt.w + 8.0 * QR_VT_DOUBLES) ;
+                st.nblk = nb ;
+            }
+        }
+        // counting sort of the workgroups by (round, launch slot): one launch per non-empty bucket
         hvec<int64_t> rptr ((size_t) nbuckets + 1, 0) ;
         // latest round of each class that some task of the bucket depends on
         hvec<int32_t> bdep ((size_t) nbuckets * QR_NCLASS, -1) ;
