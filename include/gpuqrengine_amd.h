@@ -135,8 +135,9 @@ int  gpuqr_profile_get (int kernel_id, double *ms, int64_t *launches, int64_t *t
 /* Execution mode: 0 = one launch per (round, kernel) on two streams (default), 1 = the whole call
  * as one persistent kernel that pulls the same task list from a device-resident work queue with
  * per-front arrival counters (the replacement of the reference's Scheduler/BucketList/LLBundle
- * loop, GPUQREngine/Source/GPUQREngine_Internal.cpp:57-73).  Environment GPUQR_MODE sets the
- * initial value. */
+ * loop, GPUQREngine/Source/GPUQREngine_Internal.cpp:57-73), 2 = the engine picks per call: the queue
+ * when the per-round launches would be badly filled (long dependency chains of small tasks), launches
+ * otherwise.  Environment GPUQR_MODE sets the initial value. */
 void gpuqr_set_mode (int mode);
 
 /* The engine keeps two streams, two events and grow-only task/VT buffers per

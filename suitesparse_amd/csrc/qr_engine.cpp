@@ -156,7 +156,8 @@ struct SchedTask
 // optional per-kernel profile (HIP events around every launch)
 // -----------------------------------------------------------------------------
 
-// 0: one launch per (round, kernel) on two streams; 1: one persistent work-queue kernel per call
+// 0: one launch per (round, kernel) on two streams; 1: one persistent work-queue kernel per call;
+// 2: the engine picks per call
 static int g_mode = -1 ;
 extern "C" void gpuqr_set_mode (int mode) { g_mode = mode ; }
 static int engine_mode (void)
@@ -765,7 +766,28 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
         if (!dc) { code = GPUQR_GPUERROR ; goto cleanup ; }
         sCompute = dc->sCompute ; sApply = dc->sApply ; sCopy = dc->sCopy ; evStart = dc->evStart ; evStop = dc->evStop ;
 
-        if (ntasks > 0 && engine_mode ( ) == 1 && !g_profile_on)
+        // How launch-bound the schedule is: time of the launches if each ran alone (a launch lasts at
+        // least as long as one of its workgroups) over the time of the same work with the chip full.
+        double launch_bound = 1 ;
+        {
+            static const double us [QR_NSLOTS] = {40, 40, 50, 62, 12, 17, 28, 80, 55, 12, 17, 28, 80} ;
+            double t_launch = 0, t_work = 0 ;
+            for (int64_t b = 0 ; b < nbuckets ; b++)
+            {
+                const int64_t n = rptr [b+1] - rptr [b] ;
+                if (n <= 0) continue ;
+                t_launch += us [b % QR_NSLOTS] * (double) ((n + 511) / 512) ;
+                t_work += us [b % QR_NSLOTS] * (double) n / 512.0 ;
+            }
+            if (t_work > 0) launch_bound = t_launch / t_work ;
+            if (getenv ("GPUQR_PLAN_STATS")) fprintf (stderr, "plan: launch-bound ratio %.2f (launch model %.1f ms, work %.1f ms)\n",
+                launch_bound, t_launch / 1e3, t_work / 1e3) ;
+        }
+        // mode 2: the work queue when the launches would be badly filled (measured: 2D 1024^2 grid,
+        // ratio 4.8, 12 % faster; one 4096 x 2048 front, ratio 11, 8 % faster; dense batch, ratio 1.6, and
+        // 3D 64^3, ratio 2.4, slower)
+        const bool use_queue = engine_mode ( ) == 1 || (engine_mode ( ) == 2 && launch_bound >= 4.0) ;
+        if (ntasks > 0 && use_queue && !g_profile_on)
         {
             // ---- one persistent kernel: the same tasks in the same order, with arrival counters ----
             // Counter c counts the finished workgroups that report to front c: its own tasks and the

@@ -69,3 +69,19 @@ def test_staged_sparse_in_queue_mode(queue_mode):
     res = spqr.factorize(sym, A)
     assert res.numStagesRun == sym.numStages
     assert (one.R != res.R).nnz == 0
+
+
+def test_auto_mode_picks_queue_for_a_chain_and_launches_for_a_batch(queue_mode):
+    rng = np.random.default_rng(3)
+    chain = [rng.standard_normal((1500, 700))]                    # one front: a long chain of small launches
+    batch = [rng.standard_normal((96, 32)) for _ in range(3000)]  # one full launch
+    queue_mode(0)
+    Rc0, sc0 = _dense(chain)
+    Rb0, sb0 = _dense(batch)
+    queue_mode(2)
+    Rc2, sc2 = _dense(chain)
+    Rb2, sb2 = _dense(batch)
+    assert sc2.numLaunches == 1 and sc0.numLaunches > 1
+    assert sb2.numLaunches == sb0.numLaunches
+    assert all(np.array_equal(a, b) for a, b in zip(Rc0, Rc2))
+    assert all(np.array_equal(a, b) for a, b in zip(Rb0, Rb2))
