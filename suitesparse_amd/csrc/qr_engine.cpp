@@ -1000,20 +1000,40 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
             hipEvent_t waited [QR_NCLASS][QR_NCLASS] ;
             for (int x = 0 ; x < QR_NCLASS ; x++) for (int y = 0 ; y < QR_NCLASS ; y++) waited [x][y] = NULL ;
             static const int slot_order [QR_NSLOTS] = {0, 1, 2, 3, 9, 10, 11, 12, 7, 4, 5, 6, 8} ;
+            // Row tiers that are neighbours in the slot order and share a class go out as one launch
+            // (slots 0..3: all panel tiers; 4..6: the small update tiers), unless the per-kernel profile
+            // wants them apart.
+            const bool merge_tiers = !g_profile_on && getenv ("GPUQR_SPLIT_TIERS") == NULL ;
             for (int32_t r = 0 ; r < nrounds ; r++)
             {
                 bool launched [QR_NCLASS] = {false, false, false} ;
                 for (int si = 0 ; si < QR_NSLOTS ; si++)
                 {
                     const int slot = slot_order [si] ;
-                    const int64_t b = (int64_t) r * QR_NSLOTS + slot ;
-                    const int64_t n = rptr [b+1] - rptr [b] ;
+                    int64_t b = (int64_t) r * QR_NSLOTS + slot ;
+                    int64_t n = rptr [b+1] - rptr [b] ;
+                    int kid = slot_kernel (slot) ;
+                    int32_t dmerged [QR_NCLASS] = {bdep [b*QR_NCLASS], bdep [b*QR_NCLASS + 1], bdep [b*QR_NCLASS + 2]} ;
+                    if (merge_tiers && (slot == 0 || slot == 4))
+                    {
+                        const int last = (slot == 0) ? 3 : 6 ;
+                        const int64_t bl = (int64_t) r * QR_NSLOTS + last ;
+                        n = rptr [bl+1] - rptr [b] ;
+                        kid = (slot == 0) ? 9 : 10 ;
+                        // a single tier keeps its own kernel (fewer registers, more workgroups per CU)
+                        int present = 0, only = slot ;
+                        for (int64_t bb = b ; bb <= bl ; bb++) if (rptr [bb+1] > rptr [bb]) { present++ ; only = (int) (bb % QR_NSLOTS) ; }
+                        if (present == 1) kid = slot_kernel (only) ;
+                        for (int64_t bb = b + 1 ; bb <= bl ; bb++)
+                            for (int c = 0 ; c < QR_NCLASS ; c++) dmerged [c] = std::max (dmerged [c], bdep [bb*QR_NCLASS + c]) ;
+                    }
+                    else if (merge_tiers && ((slot >= 1 && slot <= 3) || slot == 5 || slot == 6)) continue ;
                     if (n <= 0) continue ;
-                    const int x = slot_class (slot), kid = slot_kernel (slot) ;
+                    const int x = slot_class (slot) ;
                     hipStream_t st = cstream [x] ;
                     for (int y = 0 ; y < QR_NCLASS ; y++)
                     {
-                        const int32_t d = bdep [b*QR_NCLASS + y] ;
+                        const int32_t d = dmerged [y] ;
                         if (y == x || d < 0 || cstream [y] == st) continue ;
                         hipEvent_t ev = evAt [y][d] ;
                         if (ev == NULL || ev == waited [x][y]) continue ;

@@ -709,6 +709,35 @@ __global__ void __launch_bounds__ (QR_THREADS, 2) k_apply (const QrTask *tasks, 
     apply_block<MT> (tasks [ref.task].u.panel, ref.blk, smem) ;
 }
 
+// All row tiers in one launch: the panel tasks of a round are few and latency-bound, so four
+// launches in a row (one per tier) cost the sum of four latencies where one launch costs the
+// longest.  The same holds for the three small tiers of the update.
+__global__ void __launch_bounds__ (QR_THREADS, 2) k_factorize_all (const QrTask *tasks, const QrRef *refs)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem [] ;
+    const QrTask &t = tasks [refs [blockIdx.x].task] ;
+    switch (__builtin_amdgcn_readfirstlane (t.tier))
+    {
+        case 0:  factorize_panel<4>  (t.u.panel, smem) ; break ;
+        case 1:  factorize_panel<8>  (t.u.panel, smem) ; break ;
+        case 2:  factorize_panel<16> (t.u.panel, smem) ; break ;
+        default: factorize_panel<32> (t.u.panel, smem) ; break ;
+    }
+}
+
+__global__ void __launch_bounds__ (QR_THREADS, 2) k_apply_small (const QrTask *tasks, const QrRef *refs)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem [] ;
+    const QrRef ref = refs [blockIdx.x] ;
+    const QrTask &t = tasks [ref.task] ;
+    switch (__builtin_amdgcn_readfirstlane (t.tier))
+    {
+        case 0:  apply_block<2> (t.u.panel, ref.blk, smem) ; break ;
+        case 1:  apply_block<4> (t.u.panel, ref.blk, smem) ; break ;
+        default: apply_block<8> (t.u.panel, ref.blk, smem) ; break ;
+    }
+}
+
 __global__ void __launch_bounds__ (QR_THREADS) k_assemble (const QrTask *tasks, const QrRef *refs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem [] ;
@@ -727,7 +756,8 @@ extern "C" int qr_task_kernel_id (int type, int tier)
 
 static size_t kernel_lds_bytes (int kid)
 {
-    if (kid < 4) return sizeof (FactorizeLds) ;
+    if (kid < 4 || kid == 9) return sizeof (FactorizeLds) ;
+    if (kid == 10) kid = 6 ;
     if (kid < 8) { size_t rows = (size_t) 32 << (kid - 4) ; return (rows + 32) * VS_LD * 8 + rows * 4 ; }
     return 2 * QR_PACK_TILE * sizeof (int) ;
 }
@@ -928,6 +958,8 @@ extern "C" hipError_t qr_launch_tasks (int kid, const QrTask *d_tasks, const QrR
         case 6: hipLaunchKernelGGL (k_apply<8>,      grid, block, lds, stream, d_tasks, d_refs) ; break ;
         case 7: hipLaunchKernelGGL (k_apply<16>,     grid, block, lds, stream, d_tasks, d_refs) ; break ;
         case 8: hipLaunchKernelGGL (k_assemble,      grid, block, lds, stream, d_tasks, d_refs) ; break ;
+        case 9:  hipLaunchKernelGGL (k_factorize_all, grid, block, lds, stream, d_tasks, d_refs) ; break ;   // tiers 0..3
+        case 10: hipLaunchKernelGGL (k_apply_small,   grid, block, lds, stream, d_tasks, d_refs) ; break ;   // tiers 0..2
         default: return hipErrorInvalidValue ;
     }
     return hipGetLastError ( ) ;
