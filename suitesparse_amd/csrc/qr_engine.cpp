@@ -712,6 +712,11 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                     pt.cb_cols /= 2 ;
                     tot *= 2 ;
                 }
+                // and a launch that fills the chip many times over takes wider blocks: V and T are
+                // staged once per workgroup, so their share of the traffic halves
+                static int wide = -1 ;
+                if (wide < 0) { const char *e = getenv ("GPUQR_WIDE_ABOVE") ; wide = e ? atoi (e) : 1536 ; }
+                if (wide > 0 && tot >= wide && pt.cb_cols == 128 && width >= 256) pt.cb_cols = 256 ;
                 const int32_t nb = (width + pt.cb_cols - 1) / pt.cb_cols ;
                 st.bytes += (double) (nb - st.nblk) * (8.0 * pt.K * pt.w + 8.0 * QR_VT_DOUBLES) ;
                 st.nblk = nb ;
