@@ -124,7 +124,7 @@ def main():
                 fronts.append(f)
             return fronts
 
-        front_sets = [make_fronts(b) for b in bufs]
+        front_sets = [ss.FrontArray(make_fronts(b)) for b in bufs]     # the Front[] a C caller would keep
 
         def prepare(i):
             bufs[i % nbuf].copy_(src)

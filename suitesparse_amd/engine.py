@@ -115,6 +115,20 @@ def _pack(fronts, keep):
     return arr
 
 
+class FrontArray:
+    """A Front[] as the C ABI sees it: the gpuqr_front structs filled once.  Callers that run the same
+    batch many times pass this instead of a list of Front objects, as a C caller would keep its array."""
+
+    def __init__(self, fronts):
+        self.fronts = list(fronts)
+        self.keep = []
+        self.arr = _pack(self.fronts, self.keep)
+        self.sparse = any(f.isSparse() or f.gpuF for f in self.fronts)
+
+    def __len__(self):
+        return len(self.fronts)
+
+
 def GPUQREngine(gpuMemorySize, userFronts, numFronts=None, Parent=None, Childp=None, Child=None, stats=None):
     """Both overloads of GPUQREngine(...) (GPUQREngine.hpp:26-43).
 
@@ -123,19 +137,25 @@ def GPUQREngine(gpuMemorySize, userFronts, numFronts=None, Parent=None, Childp=N
     overload runs on caller-owned device buffers.
     """
     L = _lib.lib()
-    fronts = list(userFronts)
-    if numFronts is None:
-        numFronts = len(fronts)
-    fronts = fronts[:numFronts]
-    keep = []
-    arr = _pack(fronts, keep)
+    if isinstance(userFronts, FrontArray):
+        fronts, arr = userFronts.fronts, userFronts.arr
+        if numFronts is None:
+            numFronts = len(fronts)
+        sparse = Parent is not None or userFronts.sparse
+    else:
+        fronts = list(userFronts)
+        if numFronts is None:
+            numFronts = len(fronts)
+        fronts = fronts[:numFronts]
+        keep = []
+        arr = _pack(fronts, keep)
+        sparse = Parent is not None or any(f.isSparse() or f.gpuF for f in fronts)
     st = _lib.Stats()
-    sparse = Parent is not None or any(f.isSparse() or f.gpuF for f in fronts)
     if sparse:
         code = L.gpuqr_factor_sparse(gpuMemorySize, arr, numFronts, None, None, None, C.byref(st))
     else:
         code = L.gpuqr_factor_dense(gpuMemorySize, arr, numFronts, C.byref(st))
-        for k, f in enumerate(fronts):
+        for k, f in enumerate(fronts[:numFronts]):
             f.rank = arr[k].rank
     if stats is not None:
         stats.kernelTime, stats.numLaunches, stats.flopsActual = st.kernelTime, st.numLaunches, st.flopsActual
