@@ -1,0 +1,125 @@
+"""Edge cases of the engine entry points on the device: degenerate fronts, invalid descriptors, a
+failing host allocator (the reference's test suite injects malloc failures the same way,
+SPQR/Tcov/qrtest.cpp), and rows padded by the caller."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import suitesparse_amd as ss
+from suitesparse_amd import _lib
+from oracle import oracle
+from tests.util import r_rel_diff, rownorm_sign
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_fronts(mats, pitch=None):
+    import torch
+    dev = torch.device("cuda:0")
+    fronts, bufs = [], []
+    for k, A in enumerate(mats):
+        m, n = A.shape
+        ld = n if pitch is None else pitch[k]
+        P = np.zeros((max(m, 1), max(ld, 1)))
+        P[:m, :n] = A
+        t = torch.from_numpy(P).to(dev)
+        f = ss.Front(k, ss.EMPTY, m, n)
+        f.ldn = ld
+        f.gpuF = t.data_ptr()
+        fronts.append(f)
+        bufs.append(t)
+    return fronts, bufs
+
+
+def test_degenerate_fronts_in_a_batch():
+    rng = np.random.default_rng(5)
+    shapes = [(0, 5), (5, 0), (1, 1), (37, 3), (2, 300), (0, 0), (64, 64)]
+    mats = [rng.standard_normal(s) for s in shapes]
+    fronts, bufs = _device_fronts(mats)
+    assert ss.GPUQREngine(0, fronts, len(fronts)) == ss.QRENGINE_SUCCESS
+    import torch
+    torch.cuda.synchronize()
+    for A, t in zip(mats, bufs):
+        m, n = A.shape
+        if m == 0 or n == 0:
+            continue
+        R = np.triu(t.cpu().numpy()[:min(m, n), :n])
+        Rref = np.triu(oracle.front_qr(A)[:min(m, n)])
+        assert r_rel_diff(R, Rref) <= 1e-12
+
+
+def test_caller_padded_rows_give_the_same_r():
+    rng = np.random.default_rng(6)
+    shapes = [(300, 77), (129, 129), (40, 203), (513, 31)]
+    mats = [rng.standard_normal(s) for s in shapes]
+    f0, b0 = _device_fronts(mats)
+    f1, b1 = _device_fronts(mats, pitch=[n + 1 + (n & 1) * 0 + 2 * k for k, (_, n) in enumerate(shapes)])
+    assert ss.GPUQREngine(0, f0, len(f0)) == ss.QRENGINE_SUCCESS
+    assert ss.GPUQREngine(0, f1, len(f1)) == ss.QRENGINE_SUCCESS
+    import torch
+    torch.cuda.synchronize()
+    for (m, n), t0, t1 in zip(shapes, b0, b1):
+        k = min(m, n)
+        R0 = np.triu(t0.cpu().numpy()[:k, :n])
+        R1 = np.triu(t1.cpu().numpy()[:k, :n])
+        assert np.array_equal(R0, R1)
+        assert np.all(t1.cpu().numpy()[:, n:] == 0)          # the padding is never written
+
+
+def test_invalid_descriptors_are_refused():
+    rng = np.random.default_rng(7)
+    fronts, bufs = _device_fronts([rng.standard_normal((8, 8)), rng.standard_normal((8, 8))])
+    fronts[1].fids = 5                                   # fids must equal the array index
+    assert ss.GPUQREngine(0, fronts, 2) == ss.QRENGINE_GPUERROR
+    fronts[1].fids = 1
+    fronts[1].pids = 1                                   # a front cannot be its own parent
+    fronts[1].sparseMeta.isSparse = True
+    assert ss.GPUQREngine(0, fronts, 2, Parent=[0], Childp=[0], Child=[0]) == ss.QRENGINE_GPUERROR
+    fronts[1].pids = ss.EMPTY
+    fronts[1].sparseMeta.isSparse = False
+    fronts[0].gpuF = 0                                   # no device buffer and no host buffer
+    L = _lib.lib()
+    arr = (_lib.FrontC * 1)()
+    arr[0].fids, arr[0].pids, arr[0].fm, arr[0].fn, arr[0].fp, arr[0].rank = 0, -1, 4, 4, 4, 4
+    assert L.gpuqr_factor_sparse(0, arr, 1, None, None, None, None) == _lib.GPUQR_GPUERROR
+
+
+def test_failing_host_allocator_reports_out_of_memory():
+    L = _lib.lib()
+    MALLOC = C.CFUNCTYPE(C.c_void_p, C.c_size_t)
+    CALLOC = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_size_t)
+    FREE = C.CFUNCTYPE(None, C.c_void_p)
+    libc = C.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes = C.c_void_p, [C.c_size_t]
+    libc.calloc.restype, libc.calloc.argtypes = C.c_void_p, [C.c_size_t, C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    budget = {"n": 0}
+
+    def my_malloc(sz):
+        budget["n"] -= 1
+        return None if budget["n"] < 0 else libc.malloc(sz)
+
+    def my_calloc(a, b):
+        budget["n"] -= 1
+        return None if budget["n"] < 0 else libc.calloc(a, b)
+
+    cbs = (MALLOC(my_malloc), CALLOC(my_calloc), FREE(lambda p: libc.free(p)))
+    L.gpuqr_set_allocator.argtypes = [MALLOC, CALLOC, FREE]
+    rng = np.random.default_rng(8)
+    A = rng.standard_normal((200, 80))
+    codes = set()
+    try:
+        for allowed in range(0, 12):
+            fronts, bufs = _device_fronts([A])
+            budget["n"] = allowed
+            L.gpuqr_set_allocator(*cbs)
+            codes.add(ss.GPUQREngine(0, fronts, 1))
+            L.gpuqr_set_allocator(MALLOC(0), CALLOC(0), FREE(0))
+    finally:
+        L.gpuqr_set_allocator(MALLOC(0), CALLOC(0), FREE(0))
+    assert ss.QRENGINE_OUTOFMEMORY in codes          # early allocations refused
+    assert codes <= {ss.QRENGINE_OUTOFMEMORY, ss.QRENGINE_SUCCESS}
+    # and the engine still works afterwards
+    fronts, bufs = _device_fronts([A])
+    assert ss.GPUQREngine(0, fronts, 1) == ss.QRENGINE_SUCCESS
