@@ -788,10 +788,11 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
             if (getenv ("GPUQR_PLAN_STATS")) fprintf (stderr, "plan: launch-bound ratio %.2f (launch model %.1f ms, work %.1f ms)\n",
                 launch_bound, t_launch / 1e3, t_work / 1e3) ;
         }
-        // mode 2: the work queue when the launches would be badly filled (measured: 2D 1024^2 grid,
-        // ratio 4.8, 12 % faster; one 4096 x 2048 front, ratio 11, 8 % faster; dense batch, ratio 1.6, and
-        // 3D 64^3, ratio 2.4, slower)
-        const bool use_queue = engine_mode ( ) == 1 || (engine_mode ( ) == 2 && launch_bound >= 4.0) ;
+        // mode 2: the work queue when the launches would be very badly filled.  Measured (queue vs
+        // launches, kernel time): 2D 256^2 grid, ratio 22: 16.2 vs 23.6 ms; one 1024 x 1024 front: 3.2 vs
+        // 3.6 ms; 2D 1024^2 grid, ratio 4.8: 155 vs 152 ms; one 4096 x 2048 front, ratio 11: 12.1 vs
+        // 11.5 ms; dense batch, ratio 1.6: 79 vs 51 ms.
+        const bool use_queue = engine_mode ( ) == 1 || (engine_mode ( ) == 2 && launch_bound >= 12.0) ;
         if (ntasks > 0 && use_queue && !g_profile_on)
         {
             // ---- one persistent kernel: the same tasks in the same order, with arrival counters ----

@@ -73,7 +73,7 @@ def test_staged_sparse_in_queue_mode(queue_mode):
 
 def test_auto_mode_picks_queue_for_a_chain_and_launches_for_a_batch(queue_mode):
     rng = np.random.default_rng(3)
-    chain = [rng.standard_normal((1500, 700))]                    # one front: a long chain of small launches
+    chain = [rng.standard_normal((700, 500))]                     # one front: a long chain of small launches
     batch = [rng.standard_normal((96, 32)) for _ in range(3000)]  # one full launch
     queue_mode(0)
     Rc0, sc0 = _dense(chain)
