@@ -1010,9 +1010,12 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
             // (slots 0..3: all panel tiers; 4..6: the small update tiers), unless the per-kernel profile
             // wants them apart.
             const bool merge_tiers = !g_profile_on && getenv ("GPUQR_SPLIT_TIERS") == NULL ;
+            static int ride_below = -1 ;
+            if (ride_below < 0) { const char *e = getenv ("GPUQR_RIDE_BELOW") ; ride_below = e ? atoi (e) : 512 ; }
             for (int32_t r = 0 ; r < nrounds ; r++)
             {
                 bool launched [QR_NCLASS] = {false, false, false} ;
+                bool rode = false ;
                 for (int si = 0 ; si < QR_NSLOTS ; si++)
                 {
                     const int slot = slot_order [si] ;
@@ -1034,6 +1037,21 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                             for (int c = 0 ; c < QR_NCLASS ; c++) dmerged [c] = std::max (dmerged [c], bdep [bb*QR_NCLASS + c]) ;
                     }
                     else if (merge_tiers && ((slot >= 1 && slot <= 3) || slot == 5 || slot == 6)) continue ;
+                    // a 256-row update launch too small to fill the chip takes the small tiers of its round
+                    // along (slots 4..7 are neighbours in the workgroup list)
+                    const int64_t b4 = (int64_t) r * QR_NSLOTS + 4, b7 = (int64_t) r * QR_NSLOTS + 7 ;
+                    const bool ride = merge_tiers && ride_below > 0 && rptr [b7+1] > rptr [b7] && rptr [b7] > rptr [b4]
+                        && rptr [b7+1] - rptr [b7] < ride_below ;
+                    if (ride && slot == 4) continue ;           // launched with slot 7
+                    if (ride && slot == 7)
+                    {
+                        rode = true ;
+                        b = b4 ;
+                        n = rptr [b7+1] - rptr [b4] ;
+                        kid = 11 ;
+                        for (int64_t bb = b4 ; bb <= b7 ; bb++)
+                            for (int c = 0 ; c < QR_NCLASS ; c++) dmerged [c] = std::max (dmerged [c], bdep [bb*QR_NCLASS + c]) ;
+                    }
                     if (n <= 0) continue ;
                     const int x = slot_class (slot) ;
                     hipStream_t st = cstream [x] ;
@@ -1075,6 +1093,13 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                         for (int c2 = 0 ; c2 < c ; c2++) if (cstream [c2] == cstream [c]) evAt [c2][r] = ev ;
                     }
                     else evAt [c][r] = (r > 0) ? evAt [c][r-1] : (hipEvent_t) NULL ;
+                }
+                if (rode)
+                {
+                    // class-2 tasks of this round ran on the bulk stream: whoever waits for class 2 of this
+                    // round waits for that launch, and the class-2 stream stays in order behind it
+                    if (cstream [2] != cstream [1]) HIP_TRY (hipStreamWaitEvent (cstream [2], evAt [1][r], 0)) ;
+                    evAt [2][r] = evAt [1][r] ;
                 }
                 if (pi < pull_order.size ( ) && std::min (final_round (pull_order [pi]), nrounds - 1) <= r)
                 {

@@ -738,6 +738,22 @@ __global__ void __launch_bounds__ (QR_THREADS, 2) k_apply_small (const QrTask *t
     }
 }
 
+// every update tier in one launch: used when the 256-row launch of a round is too small to fill the
+// chip, so that the small tiers ride along instead of waiting for it
+__global__ void __launch_bounds__ (QR_THREADS, 2) k_apply_all (const QrTask *tasks, const QrRef *refs)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem [] ;
+    const QrRef ref = refs [blockIdx.x] ;
+    const QrTask &t = tasks [ref.task] ;
+    switch (__builtin_amdgcn_readfirstlane (t.tier))
+    {
+        case 0:  apply_block<2>  (t.u.panel, ref.blk, smem) ; break ;
+        case 1:  apply_block<4>  (t.u.panel, ref.blk, smem) ; break ;
+        case 2:  apply_block<8>  (t.u.panel, ref.blk, smem) ; break ;
+        default: apply_block<16> (t.u.panel, ref.blk, smem) ; break ;
+    }
+}
+
 __global__ void __launch_bounds__ (QR_THREADS) k_assemble (const QrTask *tasks, const QrRef *refs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem [] ;
@@ -758,6 +774,7 @@ static size_t kernel_lds_bytes (int kid)
 {
     if (kid < 4 || kid == 9) return sizeof (FactorizeLds) ;
     if (kid == 10) kid = 6 ;
+    if (kid == 11) kid = 7 ;
     if (kid < 8) { size_t rows = (size_t) 32 << (kid - 4) ; return (rows + 32) * VS_LD * 8 + rows * 4 ; }
     return 2 * QR_PACK_TILE * sizeof (int) ;
 }
@@ -960,6 +977,7 @@ extern "C" hipError_t qr_launch_tasks (int kid, const QrTask *d_tasks, const QrR
         case 8: hipLaunchKernelGGL (k_assemble,      grid, block, lds, stream, d_tasks, d_refs) ; break ;
         case 9:  hipLaunchKernelGGL (k_factorize_all, grid, block, lds, stream, d_tasks, d_refs) ; break ;   // tiers 0..3
         case 10: hipLaunchKernelGGL (k_apply_small,   grid, block, lds, stream, d_tasks, d_refs) ; break ;   // tiers 0..2
+        case 11: hipLaunchKernelGGL (k_apply_all,     grid, block, lds, stream, d_tasks, d_refs) ; break ;   // tiers 0..3
         default: return hipErrorInvalidValue ;
     }
     return hipGetLastError ( ) ;
@@ -969,6 +987,9 @@ extern "C" hipError_t qr_kernels_init (void)
 {
     // dynamic LDS above 64 KB needs an explicit opt-in on HIP
     hipError_t e = hipFuncSetAttribute ((const void *) k_apply<16>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int) kernel_lds_bytes (7)) ;
+    if (e != hipSuccess) return e ;
+    e = hipFuncSetAttribute ((const void *) k_apply_all,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int) kernel_lds_bytes (7)) ;
     if (e != hipSuccess) return e ;
     return hipFuncSetAttribute ((const void *) k_persistent,
