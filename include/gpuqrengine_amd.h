@@ -125,7 +125,8 @@ void gpuqr_set_allocator (void *(*malloc_fn) (size_t), void *(*calloc_fn) (size_
  * the stream they run on (no counterpart in the reference beyond its -DTIMING
  * total, GPUQREngine/Source/Scheduler/Scheduler_LaunchKernel.cpp:46-64).
  * Kernel ids: 0..3 factorize (32/64/128/256-row tiers), 4..7 apply (same
- * tiers), 8 assembly.  While enabled every engine call adds to the totals:
+ * tiers), 8 assembly, 9 factorize launches that mix tiers, 10 apply launches that mix the three
+ * small tiers, 11 apply launches that mix all tiers.  While enabled every engine call adds to the totals:
  * launch time in ms, launches, tasks, algorithmic flops and bytes. */
 void gpuqr_profile_enable (int on);
 void gpuqr_profile_reset (void);

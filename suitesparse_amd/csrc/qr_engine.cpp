@@ -39,7 +39,7 @@ extern "C" hipError_t qr_kernels_init (void) ;
 extern "C" hipError_t qr_launch_persistent (const QrTask *d_tasks, const QrQueueRef *d_refs, int nrefs,
     int *d_counters, int nworkgroups, hipStream_t stream) ;
 
-#define QR_NKERNELS 9
+#define QR_NKERNELS 12     // 0..8 one per task kind and tier; 9..11 the launches that merge tiers
 
 // -----------------------------------------------------------------------------
 // allocator hooks
@@ -563,7 +563,9 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
     hipEvent_t evStart = NULL, evStop = NULL ;
     DeviceCache *dc = NULL ;
     hvec<hipEvent_t> evProf ;
-    hvec<int64_t> evProfBucket ;
+    hvec<int64_t> evProfBucket ;      // per profiled launch: first bucket, workgroups, kernel id
+    hvec<int64_t> evProfN ;
+    hvec<int> evProfKid ;
     int64_t launches = 0 ;
     float ms = 0 ;
 
@@ -1009,7 +1011,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
             // Row tiers that are neighbours in the slot order and share a class go out as one launch
             // (slots 0..3: all panel tiers; 4..6: the small update tiers), unless the per-kernel profile
             // wants them apart.
-            const bool merge_tiers = !g_profile_on && getenv ("GPUQR_SPLIT_TIERS") == NULL ;
+            const bool merge_tiers = getenv ("GPUQR_SPLIT_TIERS") == NULL ;
             static int ride_below = -1 ;
             if (ride_below < 0) { const char *e = getenv ("GPUQR_RIDE_BELOW") ; ride_below = e ? atoi (e) : 512 ; }
             for (int32_t r = 0 ; r < nrounds ; r++)
@@ -1069,7 +1071,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                         hipEvent_t e0, e1 ;
                         HIP_TRY (hipEventCreate (&e0)) ; evProf.push_back (e0) ;
                         HIP_TRY (hipEventCreate (&e1)) ; evProf.push_back (e1) ;
-                        evProfBucket.push_back (b) ;
+                        evProfBucket.push_back (b) ; evProfN.push_back (n) ; evProfKid.push_back (kid) ;
                         HIP_TRY (hipEventRecord (e0, st)) ;
                         HIP_TRY (qr_launch_tasks (kid, d_tasks, d_refs + rptr [b], (int) n, st)) ;
                         HIP_TRY (hipEventRecord (e1, st)) ;
@@ -1131,11 +1133,14 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
                 float t = 0 ;
                 HIP_TRY (hipEventElapsedTime (&t, evProf [2*i], evProf [2*i+1])) ;
                 const int64_t b = evProfBucket [i] ;
-                KernelProfile &kp = g_profile [slot_kernel ((int) (b % QR_NSLOTS))] ;
-                kp.ms += t ; kp.launches++ ; kp.tasks += rptr [b+1] - rptr [b] ;      // workgroups
-                if (dump) fprintf (dump, "%ld %d %ld %.3f %.0f\n", (long) (b / QR_NSLOTS), (int) (b % QR_NSLOTS),
-                    (long) (rptr [b+1] - rptr [b]), t * 1e3, bflops [b]) ;
-                kp.flops += bflops [b] ; kp.bytes += bbytes [b] ;
+                KernelProfile &kp = g_profile [evProfKid [i]] ;
+                // a merged launch covers the neighbouring buckets up to its workgroup count
+                double fl = 0, by = 0 ;
+                for (int64_t bb = b ; bb < nbuckets && rptr [bb] < rptr [b] + evProfN [i] ; bb++) { fl += bflops [bb] ; by += bbytes [bb] ; }
+                kp.ms += t ; kp.launches++ ; kp.tasks += evProfN [i] ;      // workgroups
+                if (dump) fprintf (dump, "%ld %d %ld %.3f %.0f\n", (long) (b / QR_NSLOTS), evProfKid [i],
+                    (long) evProfN [i], t * 1e3, fl) ;
+                kp.flops += fl ; kp.bytes += by ;
             }
             if (dump) fclose (dump) ;
         }
