@@ -110,6 +110,17 @@ int64_t *gpuqr_find_staircase (const double *F, int64_t fm, int64_t fn);
  * the staging arithmetic only; the engine's own task list is not bounded by it. */
 size_t gpuqr_max_queue_size (size_t gpuMemorySize);
 
+/* gpuqr_factor_sparse for callers that factorize the same problem again and again (same fronts, same
+ * shapes, staircases, tree and device pointers; only the numbers in the fronts change), the usual
+ * case of a sparse factorization inside an iteration.  A nonzero plan_key is the caller's promise that
+ * every call made with it describes that one problem: the engine then builds and uploads its schedule
+ * once and replays it while no call with another key (or none) has intervened on the device.  No
+ * counterpart in the reference, which rebuilds its Scheduler on every call
+ * (GPUQREngine/Source/GPUQREngine_Internal.cpp:34-51).  plan_key = 0 behaves as gpuqr_factor_sparse. */
+int gpuqr_factor_sparse_keyed (size_t gpuMemorySize, gpuqr_front *fronts, int64_t numFronts,
+                               const int64_t *Parent, const int64_t *Childp, const int64_t *Child,
+                               gpuqr_stats *stats, uint64_t plan_key);
+
 /* Exact flop count of the schedule the engine would run for one fm-by-fn
  * front with staircase Stair (NULL = full), the analogue of getFlops
  * (GPUQREngine/Source/TaskDescriptor/TaskDescriptor_flops.cpp:70-104). */

@@ -435,9 +435,24 @@ extern "C" int64_t gpuqr_front_flops (int64_t fm, int64_t fn, const int64_t *Sta
 // engine does it only when a call needs more than any earlier one
 // -----------------------------------------------------------------------------
 
+// What the launch loop needs of a schedule; kept per device so that a caller who promises an
+// unchanged problem (same key) skips planning, sorting and the upload.
+struct LaunchPlan
+{
+    hvec<int64_t> rptr ;            // first workgroup of every (round, slot) bucket
+    hvec<int32_t> bdep ;            // per bucket and class: latest round depended on
+    hvec<int32_t> done_last ;       // per front and class: latest round used
+    int32_t nrounds = 0 ;
+    int64_t nbuckets = 0, ntasks = 0, nrefs = 0 ;
+    int64_t flops = 0 ;
+} ;
+
 struct DeviceCache
 {
     bool ready = false ;
+    LaunchPlan lp ;
+    uint64_t plan_key = 0 ;         // key of the schedule whose tasks sit in d_tasks / d_refs (0: none)
+    int64_t plan_nf = 0 ;
     hipStream_t sCompute = NULL, sApply = NULL, sSmall = NULL, sCopy = NULL ;
     hipEvent_t evStart = NULL, evStop = NULL ;
     std::vector<hipEvent_t> evPool ;        // untimed events, reused by every call
@@ -550,7 +565,237 @@ static double eng_now_ms (void)
 // GPUQR_VERBOSE=2 prints where the host time of an engine call goes
 #define ENG_TICK(label) do { if (eng_verbose) { double t_ = eng_now_ms ( ) ; fprintf (stderr, "    [engine] %-24s %9.2f ms\n", label, t_ - eng_tlast) ; eng_tlast = t_ ; } } while (0)
 
-static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
+// Queue the launches of the schedule in dc->lp (tasks and workgroup lists already on their way to
+// the device on the critical stream) and wait for them.
+static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, const hvec<double> &bflops,
+    const hvec<double> &bbytes, gpuqr_stats *stats, const bool eng_verbose, double &eng_tlast)
+{
+    int code = GPUQR_SUCCESS ;
+    const LaunchPlan &lp = dc->lp ;
+    const hvec<int64_t> &rptr = lp.rptr ;
+    const hvec<int32_t> &bdep = lp.bdep, &done_last = lp.done_last ;
+    const int32_t nrounds = lp.nrounds ;
+    const int64_t nbuckets = lp.nbuckets ;
+    QrTask *d_tasks = (QrTask *) dc->d_tasks ;
+    QrRef *d_refs = (QrRef *) dc->d_refs ;
+    hipStream_t sCompute = dc->sCompute, sApply = dc->sApply, sCopy = dc->sCopy ;
+    hipEvent_t evStart = dc->evStart, evStop = dc->evStop ;
+    hvec<hipEvent_t> evProf ;
+    hvec<int64_t> evProfBucket ;      // per profiled launch: first bucket, workgroups, kernel id
+    hvec<int64_t> evProfN ;
+    hvec<int> evProfKid ;
+    int64_t launches = 0 ;
+    float ms = 0 ;
+    try
+    {
+        {
+            // ---- fronts grouped by the round after which their data is final -------------
+            auto final_round = [&] (int64_t f)
+            {
+                const int32_t *d = &done_last [f*QR_NCLASS] ;
+                return std::max (0, std::max (d [0], std::max (d [1], d [2]))) ;
+            } ;
+            hvec<int64_t> pull_order ;
+            for (int64_t f = 0 ; f < nf ; f++)
+                if (fronts [f].cpuR != NULL && !(fronts [f].is_sparse && fronts [f].push_only)) pull_order.push_back (f) ;
+            std::sort (pull_order.begin ( ), pull_order.end ( ), [&] (int64_t a, int64_t b)
+                {
+                    int32_t ra = std::min (final_round (a), nrounds - 1), rb = std::min (final_round (b), nrounds - 1) ;
+                    return (ra != rb) ? (ra < rb) : (a < b) ;
+                }) ;
+
+            // Three compute streams, one per class.  The launches of a class are queued in round
+            // order; before a launch its stream waits for the event of the latest round of each
+            // other class that the tasks of the launch depend on, and for nothing else.
+            // (classes 0 and 2 share a stream unless GPUQR_STREAMS=3: every stream costs the process a
+            // hardware queue, and with several processes on one device a fifth queue per process was
+            // seen to stall the whole device)
+            static int nstreams = 0 ;
+            if (nstreams == 0) { const char *e = getenv ("GPUQR_STREAMS") ; nstreams = (e && atoi (e) == 3) ? 3 : 2 ; }
+            // Class 2 joins the lighter of the two streams.  Rough launch times (us per 512 workgroups,
+            // measured): factorize 40/40/50/62 by tier, updates 12/17/28/80 by tier.
+            int small_on ;
+            {
+                static const double us [QR_NSLOTS] = {40, 40, 50, 62, 12, 17, 28, 80, 55, 12, 17, 28, 80} ;
+                double est [QR_NCLASS] = {0, 0, 0} ;
+                for (int64_t b = 0 ; b < nbuckets ; b++)
+                {
+                    const int64_t n = rptr [b+1] - rptr [b] ;
+                    if (n > 0) est [slot_class ((int) (b % QR_NSLOTS))] += us [b % QR_NSLOTS] * (double) ((n + 511) / 512) ;
+                }
+                small_on = est [1] < est [0] ;
+                const char *e = getenv ("GPUQR_SMALL_ON") ;
+                if (e) small_on = atoi (e) ;
+            }
+            hipStream_t cstream [QR_NCLASS] = {sCompute, sApply, (nstreams == 3) ? dc->sSmall : (small_on ? sApply : sCompute)} ;
+            HIP_TRY (hipEventRecord (evStart, sCompute)) ;
+            for (int c = 1 ; c < QR_NCLASS ; c++) HIP_TRY (hipStreamWaitEvent (cstream [c], evStart, 0)) ;    // the task upload
+            size_t pi = 0, nev = 0 ;
+            // evAt [c][r]: event recorded after the last launch of class c in the latest round <= r that had one
+            hvec<hipEvent_t> evAt [QR_NCLASS] ;
+            for (int c = 0 ; c < QR_NCLASS ; c++) evAt [c].assign ((size_t) nrounds, (hipEvent_t) NULL) ;
+            hipEvent_t waited [QR_NCLASS][QR_NCLASS] ;
+            for (int x = 0 ; x < QR_NCLASS ; x++) for (int y = 0 ; y < QR_NCLASS ; y++) waited [x][y] = NULL ;
+            static const int slot_order [QR_NSLOTS] = {0, 1, 2, 3, 9, 10, 11, 12, 7, 4, 5, 6, 8} ;
+            // Row tiers that are neighbours in the slot order and share a class go out as one launch
+            // (slots 0..3: all panel tiers; 4..6: the small update tiers), unless the per-kernel profile
+            // wants them apart.
+            const bool merge_tiers = getenv ("GPUQR_SPLIT_TIERS") == NULL ;
+            static int ride_below = -1 ;
+            if (ride_below < 0) { const char *e = getenv ("GPUQR_RIDE_BELOW") ; ride_below = e ? atoi (e) : 512 ; }
+            for (int32_t r = 0 ; r < nrounds ; r++)
+            {
+                bool launched [QR_NCLASS] = {false, false, false} ;
+                bool rode = false ;
+                for (int si = 0 ; si < QR_NSLOTS ; si++)
+                {
+                    const int slot = slot_order [si] ;
+                    int64_t b = (int64_t) r * QR_NSLOTS + slot ;
+                    int64_t n = rptr [b+1] - rptr [b] ;
+                    int kid = slot_kernel (slot) ;
+                    int32_t dmerged [QR_NCLASS] = {bdep [b*QR_NCLASS], bdep [b*QR_NCLASS + 1], bdep [b*QR_NCLASS + 2]} ;
+                    if (merge_tiers && (slot == 0 || slot == 4))
+                    {
+                        const int last = (slot == 0) ? 3 : 6 ;
+                        const int64_t bl = (int64_t) r * QR_NSLOTS + last ;
+                        n = rptr [bl+1] - rptr [b] ;
+                        kid = (slot == 0) ? 9 : 10 ;
+                        // a single tier keeps its own kernel (fewer registers, more workgroups per CU)
+                        int present = 0, only = slot ;
+                        for (int64_t bb = b ; bb <= bl ; bb++) if (rptr [bb+1] > rptr [bb]) { present++ ; only = (int) (bb % QR_NSLOTS) ; }
+                        if (present == 1) kid = slot_kernel (only) ;
+                        for (int64_t bb = b + 1 ; bb <= bl ; bb++)
+                            for (int c = 0 ; c < QR_NCLASS ; c++) dmerged [c] = std::max (dmerged [c], bdep [bb*QR_NCLASS + c]) ;
+                    }
+                    else if (merge_tiers && ((slot >= 1 && slot <= 3) || slot == 5 || slot == 6)) continue ;
+                    // a 256-row update launch too small to fill the chip takes the small tiers of its round
+                    // along (slots 4..7 are neighbours in the workgroup list)
+                    const int64_t b4 = (int64_t) r * QR_NSLOTS + 4, b7 = (int64_t) r * QR_NSLOTS + 7 ;
+                    const bool ride = merge_tiers && ride_below > 0 && rptr [b7+1] > rptr [b7] && rptr [b7] > rptr [b4]
+                        && rptr [b7+1] - rptr [b7] < ride_below ;
+                    if (ride && slot == 4) continue ;           // launched with slot 7
+                    if (ride && slot == 7)
+                    {
+                        rode = true ;
+                        b = b4 ;
+                        n = rptr [b7+1] - rptr [b4] ;
+                        kid = 11 ;
+                        for (int64_t bb = b4 ; bb <= b7 ; bb++)
+                            for (int c = 0 ; c < QR_NCLASS ; c++) dmerged [c] = std::max (dmerged [c], bdep [bb*QR_NCLASS + c]) ;
+                    }
+                    if (n <= 0) continue ;
+                    const int x = slot_class (slot) ;
+                    hipStream_t st = cstream [x] ;
+                    for (int y = 0 ; y < QR_NCLASS ; y++)
+                    {
+                        const int32_t d = dmerged [y] ;
+                        if (y == x || d < 0 || cstream [y] == st) continue ;
+                        hipEvent_t ev = evAt [y][d] ;
+                        if (ev == NULL || ev == waited [x][y]) continue ;
+                        HIP_TRY (hipStreamWaitEvent (st, ev, 0)) ;
+                        waited [x][y] = ev ;
+                    }
+                    if (g_profile_on)
+                    {
+                        hipEvent_t e0, e1 ;
+                        HIP_TRY (hipEventCreate (&e0)) ; evProf.push_back (e0) ;
+                        HIP_TRY (hipEventCreate (&e1)) ; evProf.push_back (e1) ;
+                        evProfBucket.push_back (b) ; evProfN.push_back (n) ; evProfKid.push_back (kid) ;
+                        HIP_TRY (hipEventRecord (e0, st)) ;
+                        HIP_TRY (qr_launch_tasks (kid, d_tasks, d_refs + rptr [b], (int) n, st)) ;
+                        HIP_TRY (hipEventRecord (e1, st)) ;
+                    }
+                    else
+                    {
+                        HIP_TRY (qr_launch_tasks (kid, d_tasks, d_refs + rptr [b], (int) n, st)) ;
+                    }
+                    launched [x] = true ;
+                    launches++ ;
+                }
+                for (int c = 0 ; c < QR_NCLASS ; c++)
+                {
+                    if (launched [c])
+                    {
+                        hipEvent_t ev = dc->pooled_event (nev++) ;
+                        if (!ev) { code = GPUQR_GPUERROR ; goto cleanup ; }
+                        HIP_TRY (hipEventRecord (ev, cstream [c])) ;
+                        evAt [c][r] = ev ;
+                        // a class that shares the stream is covered by the same event
+                        for (int c2 = 0 ; c2 < c ; c2++) if (cstream [c2] == cstream [c]) evAt [c2][r] = ev ;
+                    }
+                    else evAt [c][r] = (r > 0) ? evAt [c][r-1] : (hipEvent_t) NULL ;
+                }
+                if (rode)
+                {
+                    // class-2 tasks of this round ran on the bulk stream: whoever waits for class 2 of this
+                    // round waits for that launch, and the class-2 stream stays in order behind it
+                    if (cstream [2] != cstream [1]) HIP_TRY (hipStreamWaitEvent (cstream [2], evAt [1][r], 0)) ;
+                    evAt [2][r] = evAt [1][r] ;
+                }
+                if (pi < pull_order.size ( ) && std::min (final_round (pull_order [pi]), nrounds - 1) <= r)
+                {
+                    for (int c = 0 ; c < QR_NCLASS ; c++) if (evAt [c][r]) HIP_TRY (hipStreamWaitEvent (sCopy, evAt [c][r], 0)) ;
+                    while (pi < pull_order.size ( ) && std::min (final_round (pull_order [pi]), nrounds - 1) <= r)
+                    {
+                        gpuqr_front &fr = fronts [pull_order [pi++]] ;
+                        int64_t nrows = fr.rank ;
+                        if (fr.is_sparse && fr.is_staged) nrows += fr.cm ;
+                        if (nrows > fr.fm) nrows = fr.fm ;
+                        HIP_TRY (pull_rows (fr, nrows, sCopy)) ;
+                    }
+                }
+            }
+            for (int c = 1 ; c < QR_NCLASS ; c++)
+                if (nrounds > 0 && evAt [c][nrounds-1]) HIP_TRY (hipStreamWaitEvent (sCompute, evAt [c][nrounds-1], 0)) ;
+            HIP_TRY (hipEventRecord (evStop, sCompute)) ;
+            ENG_TICK ("launch loop (host)") ;
+            HIP_TRY (hipStreamSynchronize (sCompute)) ;
+            HIP_TRY (hipStreamSynchronize (sApply)) ;
+            if (dc->sSmall) HIP_TRY (hipStreamSynchronize (dc->sSmall)) ;
+            HIP_TRY (hipStreamSynchronize (sCopy)) ;
+            HIP_TRY (hipEventElapsedTime (&ms, evStart, evStop)) ;
+            ENG_TICK ("wait for the device") ;
+            // GPUQR_PROFILE_DUMP=path: one line per launch (round, kernel id, workgroups, microseconds, flops)
+            FILE *dump = (g_profile_on && getenv ("GPUQR_PROFILE_DUMP")) ? fopen (getenv ("GPUQR_PROFILE_DUMP"), "w") : NULL ;
+            for (size_t i = 0 ; i < evProfBucket.size ( ) ; i++)
+            {
+                float t = 0 ;
+                HIP_TRY (hipEventElapsedTime (&t, evProf [2*i], evProf [2*i+1])) ;
+                const int64_t b = evProfBucket [i] ;
+                KernelProfile &kp = g_profile [evProfKid [i]] ;
+                // a merged launch covers the neighbouring buckets up to its workgroup count
+                double fl = 0, by = 0 ;
+                for (int64_t bb = b ; bb < nbuckets && rptr [bb] < rptr [b] + evProfN [i] ; bb++) { fl += bflops [bb] ; by += bbytes [bb] ; }
+                kp.ms += t ; kp.launches++ ; kp.tasks += evProfN [i] ;      // workgroups
+                if (dump) fprintf (dump, "%ld %d %ld %.3f %.0f\n", (long) (b / QR_NSLOTS), evProfKid [i],
+                    (long) evProfN [i], t * 1e3, fl) ;
+                kp.flops += fl ; kp.bytes += by ;
+            }
+            if (dump) fclose (dump) ;
+        }
+        if (stats)
+        {
+            stats->kernelTime = ms ;
+            stats->numLaunches = launches ;
+            stats->flopsActual = lp.flops ;
+        }
+    }
+    catch (std::bad_alloc &)
+    {
+        code = GPUQR_OUTOFMEMORY ;
+    }
+
+cleanup:
+    (void) hipStreamSynchronize (sCompute) ;
+    (void) hipStreamSynchronize (sApply) ;
+    if (dc->sSmall) (void) hipStreamSynchronize (dc->sSmall) ;
+    (void) hipStreamSynchronize (sCopy) ;
+    for (size_t i = 0 ; i < evProf.size ( ) ; i++) (void) hipEventDestroy (evProf [i]) ;
+    if (code != GPUQR_SUCCESS) dc->plan_key = 0 ;
+    return code ;
+}
+
+static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint64_t plan_key)
 {
     const char *eng_env = getenv ("GPUQR_VERBOSE") ;
     const bool eng_verbose = eng_env && atoi (eng_env) >= 2 ;
@@ -562,15 +807,24 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
     hipStream_t sCompute = NULL, sApply = NULL, sCopy = NULL ;
     hipEvent_t evStart = NULL, evStop = NULL ;
     DeviceCache *dc = NULL ;
-    hvec<hipEvent_t> evProf ;
-    hvec<int64_t> evProfBucket ;      // per profiled launch: first bucket, workgroups, kernel id
-    hvec<int64_t> evProfN ;
-    hvec<int> evProfKid ;
     int64_t launches = 0 ;
     float ms = 0 ;
 
     if (stats) { stats->kernelTime = 0 ; stats->numLaunches = 0 ; stats->flopsActual = 0 ; }
     if (nf <= 0) return GPUQR_SUCCESS ;
+    dc = device_cache ( ) ;
+    if (!dc) return GPUQR_GPUERROR ;
+    LaunchPlan &lp = dc->lp ;
+
+    // The caller vouches, by passing the same nonzero key, that nothing about the problem but the
+    // values in the fronts has changed since the call that left its schedule on the device.
+    if (plan_key != 0 && dc->plan_key == plan_key && dc->plan_nf == nf && engine_mode ( ) == 0 && !g_profile_on
+        && lp.ntasks > 0)
+    {
+        hvec<double> none ;
+        return launch_rounds (dc, fronts, nf, none, none, stats, eng_verbose, eng_tlast) ;
+    }
+    dc->plan_key = 0 ;          // the device buffers are about to be overwritten
 
     try
     {
@@ -769,8 +1023,6 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
         }
 
         ENG_TICK ("bucket sort") ;
-        dc = device_cache ( ) ;
-        if (!dc) { code = GPUQR_GPUERROR ; goto cleanup ; }
         sCompute = dc->sCompute ; sApply = dc->sApply ; sCopy = dc->sCopy ; evStart = dc->evStart ; evStop = dc->evStop ;
 
         // How launch-bound the schedule is: time of the launches if each ran alone (a launch lasts at
@@ -960,189 +1212,11 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
             HIP_TRY (hipMemcpyAsync (d_tasks, h_tasks, task_bytes, hipMemcpyHostToDevice, sCompute)) ;
             HIP_TRY (hipMemcpyAsync (d_refs, h_refs, ref_bytes, hipMemcpyHostToDevice, sCompute)) ;
 
-            // ---- fronts grouped by the round after which their data is final -------------
-            auto final_round = [&] (int64_t f)
-            {
-                const int32_t *d = &done_last [f*QR_NCLASS] ;
-                return std::max (0, std::max (d [0], std::max (d [1], d [2]))) ;
-            } ;
-            hvec<int64_t> pull_order ;
-            for (int64_t f = 0 ; f < nf ; f++)
-                if (fronts [f].cpuR != NULL && !(fronts [f].is_sparse && fronts [f].push_only)) pull_order.push_back (f) ;
-            std::sort (pull_order.begin ( ), pull_order.end ( ), [&] (int64_t a, int64_t b)
-                {
-                    int32_t ra = std::min (final_round (a), nrounds - 1), rb = std::min (final_round (b), nrounds - 1) ;
-                    return (ra != rb) ? (ra < rb) : (a < b) ;
-                }) ;
-
-            // Three compute streams, one per class.  The launches of a class are queued in round
-            // order; before a launch its stream waits for the event of the latest round of each
-            // other class that the tasks of the launch depend on, and for nothing else.
-            // (classes 0 and 2 share a stream unless GPUQR_STREAMS=3: every stream costs the process a
-            // hardware queue, and with several processes on one device a fifth queue per process was
-            // seen to stall the whole device)
-            static int nstreams = 0 ;
-            if (nstreams == 0) { const char *e = getenv ("GPUQR_STREAMS") ; nstreams = (e && atoi (e) == 3) ? 3 : 2 ; }
-            // Class 2 joins the lighter of the two streams.  Rough launch times (us per 512 workgroups,
-            // measured): factorize 40/40/50/62 by tier, updates 12/17/28/80 by tier.
-            int small_on ;
-            {
-                static const double us [QR_NSLOTS] = {40, 40, 50, 62, 12, 17, 28, 80, 55, 12, 17, 28, 80} ;
-                double est [QR_NCLASS] = {0, 0, 0} ;
-                for (int64_t b = 0 ; b < nbuckets ; b++)
-                {
-                    const int64_t n = rptr [b+1] - rptr [b] ;
-                    if (n > 0) est [slot_class ((int) (b % QR_NSLOTS))] += us [b % QR_NSLOTS] * (double) ((n + 511) / 512) ;
-                }
-                small_on = est [1] < est [0] ;
-                const char *e = getenv ("GPUQR_SMALL_ON") ;
-                if (e) small_on = atoi (e) ;
-            }
-            hipStream_t cstream [QR_NCLASS] = {sCompute, sApply, (nstreams == 3) ? dc->sSmall : (small_on ? sApply : sCompute)} ;
-            HIP_TRY (hipEventRecord (evStart, sCompute)) ;
-            for (int c = 1 ; c < QR_NCLASS ; c++) HIP_TRY (hipStreamWaitEvent (cstream [c], evStart, 0)) ;    // the task upload
-            size_t pi = 0, nev = 0 ;
-            // evAt [c][r]: event recorded after the last launch of class c in the latest round <= r that had one
-            hvec<hipEvent_t> evAt [QR_NCLASS] ;
-            for (int c = 0 ; c < QR_NCLASS ; c++) evAt [c].assign ((size_t) nrounds, (hipEvent_t) NULL) ;
-            hipEvent_t waited [QR_NCLASS][QR_NCLASS] ;
-            for (int x = 0 ; x < QR_NCLASS ; x++) for (int y = 0 ; y < QR_NCLASS ; y++) waited [x][y] = NULL ;
-            static const int slot_order [QR_NSLOTS] = {0, 1, 2, 3, 9, 10, 11, 12, 7, 4, 5, 6, 8} ;
-            // Row tiers that are neighbours in the slot order and share a class go out as one launch
-            // (slots 0..3: all panel tiers; 4..6: the small update tiers), unless the per-kernel profile
-            // wants them apart.
-            const bool merge_tiers = getenv ("GPUQR_SPLIT_TIERS") == NULL ;
-            static int ride_below = -1 ;
-            if (ride_below < 0) { const char *e = getenv ("GPUQR_RIDE_BELOW") ; ride_below = e ? atoi (e) : 512 ; }
-            for (int32_t r = 0 ; r < nrounds ; r++)
-            {
-                bool launched [QR_NCLASS] = {false, false, false} ;
-                bool rode = false ;
-                for (int si = 0 ; si < QR_NSLOTS ; si++)
-                {
-                    const int slot = slot_order [si] ;
-                    int64_t b = (int64_t) r * QR_NSLOTS + slot ;
-                    int64_t n = rptr [b+1] - rptr [b] ;
-                    int kid = slot_kernel (slot) ;
-                    int32_t dmerged [QR_NCLASS] = {bdep [b*QR_NCLASS], bdep [b*QR_NCLASS + 1], bdep [b*QR_NCLASS + 2]} ;
-                    if (merge_tiers && (slot == 0 || slot == 4))
-                    {
-                        const int last = (slot == 0) ? 3 : 6 ;
-                        const int64_t bl = (int64_t) r * QR_NSLOTS + last ;
-                        n = rptr [bl+1] - rptr [b] ;
-                        kid = (slot == 0) ? 9 : 10 ;
-                        // a single tier keeps its own kernel (fewer registers, more workgroups per CU)
-                        int present = 0, only = slot ;
-                        for (int64_t bb = b ; bb <= bl ; bb++) if (rptr [bb+1] > rptr [bb]) { present++ ; only = (int) (bb % QR_NSLOTS) ; }
-                        if (present == 1) kid = slot_kernel (only) ;
-                        for (int64_t bb = b + 1 ; bb <= bl ; bb++)
-                            for (int c = 0 ; c < QR_NCLASS ; c++) dmerged [c] = std::max (dmerged [c], bdep [bb*QR_NCLASS + c]) ;
-                    }
-                    else if (merge_tiers && ((slot >= 1 && slot <= 3) || slot == 5 || slot == 6)) continue ;
-                    // a 256-row update launch too small to fill the chip takes the small tiers of its round
-                    // along (slots 4..7 are neighbours in the workgroup list)
-                    const int64_t b4 = (int64_t) r * QR_NSLOTS + 4, b7 = (int64_t) r * QR_NSLOTS + 7 ;
-                    const bool ride = merge_tiers && ride_below > 0 && rptr [b7+1] > rptr [b7] && rptr [b7] > rptr [b4]
-                        && rptr [b7+1] - rptr [b7] < ride_below ;
-                    if (ride && slot == 4) continue ;           // launched with slot 7
-                    if (ride && slot == 7)
-                    {
-                        rode = true ;
-                        b = b4 ;
-                        n = rptr [b7+1] - rptr [b4] ;
-                        kid = 11 ;
-                        for (int64_t bb = b4 ; bb <= b7 ; bb++)
-                            for (int c = 0 ; c < QR_NCLASS ; c++) dmerged [c] = std::max (dmerged [c], bdep [bb*QR_NCLASS + c]) ;
-                    }
-                    if (n <= 0) continue ;
-                    const int x = slot_class (slot) ;
-                    hipStream_t st = cstream [x] ;
-                    for (int y = 0 ; y < QR_NCLASS ; y++)
-                    {
-                        const int32_t d = dmerged [y] ;
-                        if (y == x || d < 0 || cstream [y] == st) continue ;
-                        hipEvent_t ev = evAt [y][d] ;
-                        if (ev == NULL || ev == waited [x][y]) continue ;
-                        HIP_TRY (hipStreamWaitEvent (st, ev, 0)) ;
-                        waited [x][y] = ev ;
-                    }
-                    if (g_profile_on)
-                    {
-                        hipEvent_t e0, e1 ;
-                        HIP_TRY (hipEventCreate (&e0)) ; evProf.push_back (e0) ;
-                        HIP_TRY (hipEventCreate (&e1)) ; evProf.push_back (e1) ;
-                        evProfBucket.push_back (b) ; evProfN.push_back (n) ; evProfKid.push_back (kid) ;
-                        HIP_TRY (hipEventRecord (e0, st)) ;
-                        HIP_TRY (qr_launch_tasks (kid, d_tasks, d_refs + rptr [b], (int) n, st)) ;
-                        HIP_TRY (hipEventRecord (e1, st)) ;
-                    }
-                    else
-                    {
-                        HIP_TRY (qr_launch_tasks (kid, d_tasks, d_refs + rptr [b], (int) n, st)) ;
-                    }
-                    launched [x] = true ;
-                    launches++ ;
-                }
-                for (int c = 0 ; c < QR_NCLASS ; c++)
-                {
-                    if (launched [c])
-                    {
-                        hipEvent_t ev = dc->pooled_event (nev++) ;
-                        if (!ev) { code = GPUQR_GPUERROR ; goto cleanup ; }
-                        HIP_TRY (hipEventRecord (ev, cstream [c])) ;
-                        evAt [c][r] = ev ;
-                        // a class that shares the stream is covered by the same event
-                        for (int c2 = 0 ; c2 < c ; c2++) if (cstream [c2] == cstream [c]) evAt [c2][r] = ev ;
-                    }
-                    else evAt [c][r] = (r > 0) ? evAt [c][r-1] : (hipEvent_t) NULL ;
-                }
-                if (rode)
-                {
-                    // class-2 tasks of this round ran on the bulk stream: whoever waits for class 2 of this
-                    // round waits for that launch, and the class-2 stream stays in order behind it
-                    if (cstream [2] != cstream [1]) HIP_TRY (hipStreamWaitEvent (cstream [2], evAt [1][r], 0)) ;
-                    evAt [2][r] = evAt [1][r] ;
-                }
-                if (pi < pull_order.size ( ) && std::min (final_round (pull_order [pi]), nrounds - 1) <= r)
-                {
-                    for (int c = 0 ; c < QR_NCLASS ; c++) if (evAt [c][r]) HIP_TRY (hipStreamWaitEvent (sCopy, evAt [c][r], 0)) ;
-                    while (pi < pull_order.size ( ) && std::min (final_round (pull_order [pi]), nrounds - 1) <= r)
-                    {
-                        gpuqr_front &fr = fronts [pull_order [pi++]] ;
-                        int64_t nrows = fr.rank ;
-                        if (fr.is_sparse && fr.is_staged) nrows += fr.cm ;
-                        if (nrows > fr.fm) nrows = fr.fm ;
-                        HIP_TRY (pull_rows (fr, nrows, sCopy)) ;
-                    }
-                }
-            }
-            for (int c = 1 ; c < QR_NCLASS ; c++)
-                if (nrounds > 0 && evAt [c][nrounds-1]) HIP_TRY (hipStreamWaitEvent (sCompute, evAt [c][nrounds-1], 0)) ;
-            HIP_TRY (hipEventRecord (evStop, sCompute)) ;
-            ENG_TICK ("launch loop (host)") ;
-            HIP_TRY (hipStreamSynchronize (sCompute)) ;
-            HIP_TRY (hipStreamSynchronize (sApply)) ;
-            if (dc->sSmall) HIP_TRY (hipStreamSynchronize (dc->sSmall)) ;
-            HIP_TRY (hipStreamSynchronize (sCopy)) ;
-            HIP_TRY (hipEventElapsedTime (&ms, evStart, evStop)) ;
-            ENG_TICK ("wait for the device") ;
-            // GPUQR_PROFILE_DUMP=path: one line per launch (round, kernel id, workgroups, microseconds, flops)
-            FILE *dump = (g_profile_on && getenv ("GPUQR_PROFILE_DUMP")) ? fopen (getenv ("GPUQR_PROFILE_DUMP"), "w") : NULL ;
-            for (size_t i = 0 ; i < evProfBucket.size ( ) ; i++)
-            {
-                float t = 0 ;
-                HIP_TRY (hipEventElapsedTime (&t, evProf [2*i], evProf [2*i+1])) ;
-                const int64_t b = evProfBucket [i] ;
-                KernelProfile &kp = g_profile [evProfKid [i]] ;
-                // a merged launch covers the neighbouring buckets up to its workgroup count
-                double fl = 0, by = 0 ;
-                for (int64_t bb = b ; bb < nbuckets && rptr [bb] < rptr [b] + evProfN [i] ; bb++) { fl += bflops [bb] ; by += bbytes [bb] ; }
-                kp.ms += t ; kp.launches++ ; kp.tasks += evProfN [i] ;      // workgroups
-                if (dump) fprintf (dump, "%ld %d %ld %.3f %.0f\n", (long) (b / QR_NSLOTS), evProfKid [i],
-                    (long) evProfN [i], t * 1e3, fl) ;
-                kp.flops += fl ; kp.bytes += by ;
-            }
-            if (dump) fclose (dump) ;
+            // the schedule is on the device: remember whose it is, then run it
+            lp.rptr.swap (rptr) ; lp.bdep.swap (bdep) ; lp.done_last.swap (done_last) ;
+            lp.nrounds = nrounds ; lp.nbuckets = nbuckets ; lp.ntasks = ntasks ; lp.nrefs = nrefs ; lp.flops = plan.flops ;
+            dc->plan_key = plan_key ; dc->plan_nf = nf ;
+            return launch_rounds (dc, fronts, nf, bflops, bbytes, stats, eng_verbose, eng_tlast) ;
         }
         if (stats)
         {
@@ -1161,9 +1235,19 @@ cleanup:
     if (sApply) (void) hipStreamSynchronize (sApply) ;
     if (dc && dc->sSmall) (void) hipStreamSynchronize (dc->sSmall) ;
     if (sCopy) (void) hipStreamSynchronize (sCopy) ;
-    for (size_t i = 0 ; i < evProf.size ( ) ; i++) (void) hipEventDestroy (evProf [i]) ;
     // streams, events and device buffers stay in the per-device cache for the next call
     return code ;
+}
+
+extern "C" int gpuqr_factor_sparse_keyed
+(
+    size_t gpuMemorySize, gpuqr_front *fronts, int64_t numFronts,
+    const int64_t *Parent, const int64_t *Childp, const int64_t *Child, gpuqr_stats *stats, uint64_t plan_key
+)
+{
+    (void) gpuMemorySize ; (void) Parent ; (void) Childp ; (void) Child ;
+    if (numFronts < 0 || (numFronts > 0 && fronts == NULL)) return GPUQR_GPUERROR ;
+    return engine_run (fronts, numFronts, stats, plan_key) ;
 }
 
 extern "C" int gpuqr_factor_sparse
@@ -1174,7 +1258,7 @@ extern "C" int gpuqr_factor_sparse
 {
     (void) gpuMemorySize ; (void) Parent ; (void) Childp ; (void) Child ;
     if (numFronts < 0 || (numFronts > 0 && fronts == NULL)) return GPUQR_GPUERROR ;
-    return engine_run (fronts, numFronts, stats) ;
+    return engine_run (fronts, numFronts, stats, 0) ;
 }
 
 // -----------------------------------------------------------------------------
@@ -1249,7 +1333,7 @@ extern "C" int gpuqr_factor_dense
     }
     if (FSize > 0 && hipMemcpy (dF, hF, FSize * sizeof (double), hipMemcpyHostToDevice) != hipSuccess) { code = GPUQR_GPUERROR ; goto cleanup ; }
 
-    code = engine_run (fronts, nf, stats) ;
+    code = engine_run (fronts, nf, stats, 0) ;
     if (code != GPUQR_SUCCESS) goto cleanup ;
 
     for (int64_t f = 0 ; f < nf ; f++)

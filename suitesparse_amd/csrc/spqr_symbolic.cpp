@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <atomic>
 #include <algorithm>
 #include <new>
 
@@ -92,6 +93,7 @@ extern "C" spqr_amd_symbolic *spqr_amd_analyze
     try
     {
         S = new spqr_amd_symbolic ( ) ;
+        { static std::atomic<uint64_t> next_uid (1) ; S->uid = next_uid.fetch_add (1) ; }
         S->m = m ; S->n = n ; S->anz = Ap [n] ;
         const Long anz = Ap [n] ;
 

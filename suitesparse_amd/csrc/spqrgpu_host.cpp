@@ -625,7 +625,19 @@ static int factorize_impl
 
             // ---- the device work ---------------------------------------------------------------
             gpuqr_stats stats ;
-            int ecode = gpuqr_factor_sparse (S->gpuMemorySize, fronts.data ( ), next_child, Parent, Childp, Child, &stats) ;
+            // One group and nothing arriving from outside it: every call on this symbolic object and
+            // these workspaces describes the same problem to the engine, which may then keep its schedule.
+            uint64_t plan_key = 0 ;
+            if (ngroups == 1 && nlimbo == 0 && getenv ("GPUQR_NO_PLAN_CACHE") == NULL)
+            {
+                const uint64_t parts [6] = {S->uid, (uint64_t) (uintptr_t) dF.p, (uint64_t) (uintptr_t) dS.p,
+                    (uint64_t) (uintptr_t) NC.d_Rimap, (uint64_t) (uintptr_t) NC.d_Rjmap, (uint64_t) numFronts} ;
+                plan_key = 1469598103934665603ull ;
+                for (int i = 0 ; i < 6 ; i++) for (int b = 0 ; b < 8 ; b++) { plan_key ^= (parts [i] >> (8*b)) & 0xff ; plan_key *= 1099511628211ull ; }
+                if (mine) for (Long f = 0 ; f < nf ; f++) { plan_key ^= (uint64_t) (mine [f] != 0) ; plan_key *= 1099511628211ull ; }
+                plan_key |= 1 ;
+            }
+            int ecode = gpuqr_factor_sparse_keyed (S->gpuMemorySize, fronts.data ( ), next_child, Parent, Childp, Child, &stats, plan_key) ;
             TICK ("engine") ;
             if (ecode != GPUQR_SUCCESS) { code = (ecode == GPUQR_OUTOFMEMORY) ? 1 : 2 ; goto done ; }
             num->gpuKernelTime += stats.kernelTime ;

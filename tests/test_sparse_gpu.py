@@ -151,3 +151,24 @@ def test_pageable_r_stack_fallback(monkeypatch):
     monkeypatch.setenv("GPUQR_PAGEABLE_R", "1")
     r1 = spqr.factorize(sym, A)
     assert (r0.R != r1.R).nnz == 0
+
+
+def test_repeated_factorizations_reuse_the_schedule_and_follow_the_values(monkeypatch):
+    """A second factorization on the same symbolic object replays the engine's schedule; it must
+    track new values, survive other engine calls in between, and agree with the uncached path."""
+    grid = (30, 30)
+    A = problems.stacked_ls(grid)
+    Q = problems.nested_dissection(grid, leaf=4)
+    sym = spqr.analyze(A, Q, relax=20, gpuMemorySize=2**34)
+    r1 = spqr.factorize(sym, A)
+    A2 = A.copy()
+    A2.data = A2.data * np.linspace(0.5, 1.5, A2.nnz)
+    r2 = spqr.factorize(sym, A2)                                    # schedule replayed, new values
+    sym_b = spqr.analyze(problems.stacked_ls((12, 12)), None, gpuMemorySize=2**34)
+    spqr.factorize(sym_b, problems.stacked_ls((12, 12)))            # another problem in between
+    r3 = spqr.factorize(sym, A)
+    monkeypatch.setenv("GPUQR_NO_PLAN_CACHE", "1")
+    r1n = spqr.factorize(sym, A)
+    r2n = spqr.factorize(sym, A2)
+    assert (r1.R != r1n.R).nnz == 0 and (r3.R != r1n.R).nnz == 0
+    assert (r2.R != r2n.R).nnz == 0 and (r2.R != r1.R).nnz > 0
