@@ -384,6 +384,16 @@ __device__ __forceinline__ d2 pair_exchange (d2 v)
     return o ;
 }
 
+// The trailing matrix streams through once per panel: with ABL_NT its accesses carry the
+// non-temporal hint.
+#ifdef ABL_NT
+#define SLAB_LOAD(p) __builtin_nontemporal_load (p)
+#define SLAB_STORE(v, p) __builtin_nontemporal_store ((v), (p))
+#else
+#define SLAB_LOAD(p) (*(p))
+#define SLAB_STORE(v, p) (*(p) = (v))
+#endif
+
 template <int MT>
 __device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk, char *smem)
 {
@@ -438,23 +448,33 @@ __device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk
 #ifdef ABL_NOMEM
                 A [mt][h] = (d2) {(double) (r + col), 1.0} ;
 #else
-                A [mt][h] = *(gd2 *) (F + (size_t) rowmap [r] * ld + lcol) ;
+                A [mt][h] = SLAB_LOAD ((gd2 *) (F + (size_t) rowmap [r] * ld + lcol)) ;
 #endif
             }
         }
     }
 
     // V and T go to LDS while the first slab is on its way
-    for (int idx = tid ; idx < MT*16*32 ; idx += QR_THREADS)
+    // two columns per lane (16 bytes, as for the slabs); col0 is a multiple of 32, so the pair never
+    // straddles the panel edge except at an odd panel width, where the second column is dropped
+    for (int idx = tid ; idx < MT*16*16 ; idx += QR_THREADS)
     {
-        int r = idx >> 5, c = idx & 31 ;
-        double val = 0 ;
+        const int r = idx >> 4, c = (idx & 15) * 2 ;
+        d2 val = {0.0, 0.0} ;
         if (r < K && c < kmax)
         {
-            if (r < w) val = (c < r) ? VT [r*32 + c] : ((c == r) ? 1.0 : 0.0) ;
-            else       val = F [(size_t) rowmap [r] * ld + t.col0 + c] ;
+            if (r < w)
+            {
+                val.x = (c < r) ? VT [r*32 + c] : ((c == r) ? 1.0 : 0.0) ;
+                val.y = (c + 1 < r) ? VT [r*32 + c + 1] : ((c + 1 == r) ? 1.0 : 0.0) ;
+            }
+            else if (c + 1 < t.ld - t.col0)
+                val = *(gd2 *) (F + (size_t) rowmap [r] * ld + t.col0 + c) ;
+            else
+                val.x = F [(size_t) rowmap [r] * ld + t.col0 + c] ;
+            if (c + 1 >= kmax) val.y = 0.0 ;
         }
-        Vs [r][c] = val ;
+        Vs [r][c] = val.x ; Vs [r][c + 1] = val.y ;
     }
     for (int idx = tid ; idx < 32*32 ; idx += QR_THREADS)
     {
@@ -538,10 +558,10 @@ __device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk
 #else
                 if (r < K)
                 {
-                    if (v1)      *(gd2 *) (rowp + col) = o ;
+                    if (v1)      SLAB_STORE (o, (gd2 *) (rowp + col)) ;
                     else if (v0) rowp [col] = o.x ;
                 }
-                A [mt][h] = *(gd2 *) (rowp + nlcol) ;
+                A [mt][h] = SLAB_LOAD ((gd2 *) (rowp + nlcol)) ;
 #endif
             }
         }
