@@ -476,10 +476,13 @@ __device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk
         }
         Vs [r][c] = val.x ; Vs [r][c + 1] = val.y ;
     }
-    for (int idx = tid ; idx < 32*32 ; idx += QR_THREADS)
+    for (int idx = tid ; idx < 32*16 ; idx += QR_THREADS)
     {
-        int r = idx >> 5, c = idx & 31 ;
-        Ts [r][c] = (c >= r && c < kmax) ? VT [r*32 + c] : 0.0 ;
+        const int r = idx >> 4, c = (idx & 15) * 2 ;
+        typedef __attribute__((address_space(1))) const d2 gcd2 ;
+        const d2 tv = *(gcd2 *) (VT + r*32 + c) ;       // the tile is 32 x 32 and 16-byte aligned
+        Ts [r][c]     = (c >= r && c < kmax) ? tv.x : 0.0 ;
+        Ts [r][c + 1] = (c + 1 >= r && c + 1 < kmax) ? tv.y : 0.0 ;
     }
     __syncthreads ( ) ;
 
