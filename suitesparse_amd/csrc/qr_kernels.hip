@@ -54,6 +54,32 @@ __device__ __forceinline__ void build_rowmap (const QrPanelTask &t, int *rowmap,
 }
 
 // -----------------------------------------------------------------------------
+// 16-byte accesses to a row-major front, one column per lane afterwards
+// -----------------------------------------------------------------------------
+
+typedef double d2 __attribute__((ext_vector_type(2))) ;
+typedef __attribute__((address_space(1))) d2 __attribute__((aligned(8))) gd2 ;  // rows of odd fn are only 8-byte aligned
+
+// old in the lanes whose bank (group of 4 lanes within a row of 16) is not in BANKS, elsewhere
+// src of the lane 8 further round the row
+template <int BANKS> __device__ __forceinline__ double row_ror8_merge (double old, double src)
+{
+    int lo = __builtin_amdgcn_update_dpp (__double2loint (old), __double2loint (src), 0x128, 0xf, BANKS, false) ;
+    int hi = __builtin_amdgcn_update_dpp (__double2hiint (old), __double2hiint (src), 0x128, 0xf, BANKS, false) ;
+    return __hiloint2double (hi, lo) ;
+}
+
+// (row r, columns c and c+1) per lane  <->  (rows r_even and r_even+1, one column) per lane; the
+// exchange is its own inverse
+__device__ __forceinline__ d2 pair_exchange (d2 v)
+{
+    d2 o ;
+    o.x = row_ror8_merge<0xC> (v.x, v.y) ;
+    o.y = row_ror8_merge<0x3> (v.y, v.x) ;
+    return o ;
+}
+
+// -----------------------------------------------------------------------------
 // factorize_panel
 // -----------------------------------------------------------------------------
 //
@@ -272,12 +298,31 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
     for (int i = tid ; i < 2*32*33 ; i += QR_THREADS) (&L.Z[0][0]) [i] = 0 ;     // Z and T
     __syncthreads ( ) ;
 
+    // Load with 16 bytes per lane: the lanes of columns c and c^1 (8 lanes apart) each fetch both
+    // columns of one of two rows, then trade one element (see pair_exchange).
     double a [RPT] ;
+    const int cb = c & ~1 ;                                     // first column of the lane's pair
+    const bool pair0 = cb < w, pair1 = (cb + 1 < w) && (t.col0 + cb + 1 < ld) ;
+    // (all loads first, the exchanges after them: an exchange waits for its load)
     #pragma unroll
-    for (int i = 0 ; i < RPT ; i++)
+    for (int i = 0 ; i < RPT ; i += 2)
     {
-        int r = rg + 8*i ;
-        a [i] = (r < K && c < w) ? F [(size_t) L.rowmap [r] * ld + t.col0 + c] : 0.0 ;
+        const int r = rg + 8 * (i + (c & 1)) ;                  // even column: first row of the two
+        d2 v = {0.0, 0.0} ;
+        if (r < K && pair0)
+        {
+            gdouble *p = F + (size_t) L.rowmap [r] * ld + t.col0 + cb ;
+            if (pair1) v = *(gd2 *) p ; else v.x = p [0] ;
+        }
+        a [i] = v.x ; a [i+1] = v.y ;
+    }
+    #pragma unroll
+    for (int i = 0 ; i < RPT ; i += 2)
+    {
+        d2 v = {a [i], a [i+1]} ;
+        v = pair_exchange (v) ;
+        a [i] = (c < w) ? v.x : 0.0 ;
+        a [i+1] = (c < w) ? v.y : 0.0 ;
     }
 
     double s_cur = 0 ;
@@ -294,21 +339,27 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
 
     // ---- write back R (zeros below the diagonal), V2 in place, V1 to the VT tile ----
     #pragma unroll
-    for (int i = 0 ; i < RPT ; i++)
+    for (int i = 0 ; i < RPT ; i += 2)
     {
-        int r = rg + 8*i ;
-        if (r < K && c < w)
+        d2 o ;
+        #pragma unroll
+        for (int e = 0 ; e < 2 ; e++)
         {
-            size_t p = (size_t) L.rowmap [r] * ld + t.col0 + c ;
+            const int r = rg + 8 * (i + e) ;
+            double val = a [i + e] ;
             if (r < w)
             {
-                F [p] = (c >= r) ? a [i] : 0.0 ;
-                if (VT != NULL && c < r) VT [r*32 + c] = a [i] ;
+                if (VT != NULL && c < r && r < K && c < w) VT [r*32 + c] = val ;
+                if (c < r) val = 0.0 ;
             }
-            else
-            {
-                F [p] = a [i] ;
-            }
+            o [e] = val ;
+        }
+        o = pair_exchange (o) ;                                 // back to (one row, two columns)
+        const int r = rg + 8 * (i + (c & 1)) ;
+        if (r < K && pair0)
+        {
+            gdouble *p = F + (size_t) L.rowmap [r] * ld + t.col0 + cb ;
+            if (pair1) *(gd2 *) p = o ; else p [0] = o.x ;
         }
     }
     FACT_TICK (3) ;
@@ -361,28 +412,6 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
 #else
 #define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64 ((a), (b), (c), 0, 0, 0)
 #endif
-
-typedef double d2 __attribute__((ext_vector_type(2))) ;
-typedef __attribute__((address_space(1))) d2 __attribute__((aligned(8))) gd2 ;  // rows of odd fn are only 8-byte aligned
-
-// old in the lanes whose bank (group of 4 lanes within a row of 16) is not in BANKS, elsewhere
-// src of the lane 8 further round the row
-template <int BANKS> __device__ __forceinline__ double row_ror8_merge (double old, double src)
-{
-    int lo = __builtin_amdgcn_update_dpp (__double2loint (old), __double2loint (src), 0x128, 0xf, BANKS, false) ;
-    int hi = __builtin_amdgcn_update_dpp (__double2hiint (old), __double2hiint (src), 0x128, 0xf, BANKS, false) ;
-    return __hiloint2double (hi, lo) ;
-}
-
-// (row r, columns c and c+1) per lane  <->  (rows r_even and r_even+1, one column) per lane; the
-// exchange is its own inverse
-__device__ __forceinline__ d2 pair_exchange (d2 v)
-{
-    d2 o ;
-    o.x = row_ror8_merge<0xC> (v.x, v.y) ;
-    o.y = row_ror8_merge<0x3> (v.y, v.x) ;
-    return o ;
-}
 
 // The trailing matrix streams through once per panel: with ABL_NT its accesses carry the
 // non-temporal hint.
