@@ -974,6 +974,9 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
                 if (wide < 0) { const char *e = getenv ("GPUQR_WIDE_ABOVE") ; wide = e ? atoi (e) : 1536 ; }
                 if (wide > 0 && tot >= wide && pt.cb_cols == 128 && width >= 256) pt.cb_cols = 256 ;
                 const int32_t nb = (width + pt.cb_cols - 1) / pt.cb_cols ;
+                // the same number of blocks, evened out (a last block of 32 columns would leave half of
+                // its workgroup's waves idle); 16-column granularity keeps the 16-byte accesses aligned
+                pt.cb_cols = (((width + nb - 1) / nb) + 15) / 16 * 16 ;
                 st.bytes += (double) (nb - st.nblk) * (8.0 * pt.K * pt.w + 8.0 * QR_VT_DOUBLES) ;
                 st.nblk = nb ;
             }
