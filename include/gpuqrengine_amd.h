@@ -66,6 +66,14 @@ typedef struct gpuqr_front
     const int32_t *gpuRjmap;  /* device, size cn: C column -> parent column */
     const int32_t *gpuRimap;  /* device, size cm: C row -> parent row */
     double *gpuC;          /* device location of C(0,0); its leading dimension is fn (cn if push_only) */
+    /* R hand-off in SPQR's stack layout, no counterpart in the reference's Front (its caller packs
+     * on the host, SPQR/SPQRGPU/spqrgpu_kernel.cpp:417-439).  When gpuRpack is set, the engine writes
+     * the first `rank` rows of the reduced front there as a column-packed upper trapezoid (column j
+     * holds min(j+1, rank) entries) as soon as the front is final; when cpuRpack is set too it copies
+     * that block to the host while other fronts are still being factorized, neighbouring blocks in
+     * one transfer.  Both NULL: nothing happens. */
+    double *gpuRpack;
+    double *cpuRpack;
 } gpuqr_front;
 
 /* same fields as QREngineStats (GPUQREngine/Include/GPUQREngine_Stats.hpp:13-29) */

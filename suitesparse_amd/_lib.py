@@ -28,6 +28,7 @@ class FrontC(C.Structure):
         ("gpuS", C.c_void_p), ("Scount", C.c_int64),
         ("cm", C.c_int32), ("cn", C.c_int32), ("pn", C.c_int32), ("pad1", C.c_int32),
         ("gpuRjmap", C.c_void_p), ("gpuRimap", C.c_void_p), ("gpuC", C.c_void_p),
+        ("gpuRpack", C.c_void_p), ("cpuRpack", C.c_void_p),
     ]
 
 

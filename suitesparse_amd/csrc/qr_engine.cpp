@@ -34,6 +34,8 @@
 #include "../../include/gpuqrengine_amd.h"
 
 extern "C" int        qr_task_kernel_id (int type, int tier) ;
+extern "C" hipError_t qr_launch_pack_r (const QrPackRTask *d_tasks, const long long *d_tile_prefix, int nfronts,
+    long long ntiles, hipStream_t stream) ;
 extern "C" hipError_t qr_launch_tasks (int kid, const QrTask *d_tasks, const QrRef *d_refs, int nrefs, hipStream_t stream) ;
 extern "C" hipError_t qr_kernels_init (void) ;
 extern "C" hipError_t qr_launch_persistent (const QrTask *d_tasks, const QrQueueRef *d_refs, int nrefs,
@@ -456,8 +458,8 @@ struct DeviceCache
     hipStream_t sCompute = NULL, sApply = NULL, sSmall = NULL, sCopy = NULL ;
     hipEvent_t evStart = NULL, evStop = NULL ;
     std::vector<hipEvent_t> evPool ;        // untimed events, reused by every call
-    void *d_tasks = NULL, *d_refs = NULL, *d_vt = NULL, *h_stage = NULL, *d_counters = NULL ;
-    size_t cap_tasks = 0, cap_refs = 0, cap_vt = 0, cap_stage = 0, cap_counters = 0 ;
+    void *d_tasks = NULL, *d_refs = NULL, *d_vt = NULL, *h_stage = NULL, *d_counters = NULL, *d_pack = NULL ;
+    size_t cap_tasks = 0, cap_refs = 0, cap_vt = 0, cap_stage = 0, cap_counters = 0, cap_pack = 0 ;
     int num_cus = 0 ;
 
     hipError_t ensure (void **p, size_t *cap, size_t need, bool pinned_host)
@@ -495,6 +497,7 @@ struct DeviceCache
         if (d_refs) (void) hipFree (d_refs) ;
         if (d_vt) (void) hipFree (d_vt) ;
         if (d_counters) (void) hipFree (d_counters) ;
+        if (d_pack) (void) hipFree (d_pack) ;
         if (h_stage) (void) hipHostFree (h_stage) ;
         *this = DeviceCache ( ) ;
     }
@@ -565,6 +568,93 @@ static double eng_now_ms (void)
 // GPUQR_VERBOSE=2 prints where the host time of an engine call goes
 #define ENG_TICK(label) do { if (eng_verbose) { double t_ = eng_now_ms ( ) ; fprintf (stderr, "    [engine] %-24s %9.2f ms\n", label, t_ - eng_tlast) ; eng_tlast = t_ ; } } while (0)
 
+// R in the caller's packed layout (gpuqr_front.gpuRpack / cpuRpack).  Fronts are grouped by the
+// rounds after which they are final; a group is packed by one launch on the copy stream and sent by
+// one copy per run of blocks that are neighbours in both address spaces, while the compute streams
+// go on with the rest of the tree.
+struct RPackOut
+{
+    struct Block { int32_t group ; int64_t f ; const char *dev ; char *host ; size_t bytes ; } ;
+    hvec<Block> blocks ;            // sorted by (group, device address)
+    hvec<long long> prefix ;        // per group: running count of 32-row tiles, restarting at 0
+    hvec<int64_t> gprefix ;         // per block: where its group's counts begin in prefix
+    const QrPackRTask *d_tasks = NULL ;
+    const long long *d_prefix = NULL ;
+    size_t pos = 0 ;
+
+    // group_of (f): group of front f; groups are issued in increasing order
+    template <typename G> hipError_t build (DeviceCache *dc, const gpuqr_front *fronts, int64_t nf, G group_of, hipStream_t stream)
+    {
+        for (int64_t f = 0 ; f < nf ; f++)
+        {
+            const gpuqr_front &fr = fronts [f] ;
+            if (fr.gpuRpack == NULL || (fr.is_sparse && fr.push_only) || fr.rank <= 0 || fr.fn <= 0 || fr.fm <= 0) continue ;
+            const int64_t rr = std::min (fr.rank, fr.fm) ;
+            Block c ;
+            c.group = group_of (f) ; c.f = f ;
+            c.dev = (const char *) fr.gpuRpack ; c.host = (char *) fr.cpuRpack ;
+            c.bytes = (size_t) (rr * (rr + 1) / 2 + rr * (fr.fn - rr)) * sizeof (double) ;
+            blocks.push_back (c) ;
+        }
+        if (blocks.empty ( )) return hipSuccess ;
+        std::sort (blocks.begin ( ), blocks.end ( ), [] (const Block &a, const Block &b)
+            { return (a.group != b.group) ? (a.group < b.group) : (a.dev < b.dev) ; }) ;
+        hvec<QrPackRTask> tasks (blocks.size ( )) ;
+        gprefix.assign (blocks.size ( ), 0) ;
+        for (size_t i = 0 ; i < blocks.size ( ) ; i++)
+        {
+            const gpuqr_front &fr = fronts [blocks [i].f] ;
+            const int64_t rr = std::min (fr.rank, fr.fm) ;
+            QrPackRTask &t = tasks [i] ;
+            t.F = fr.gpuF ; t.out = fr.gpuRpack ; t.ld = (int32_t) front_pitch (fr) ; t.fn = (int32_t) fr.fn ;
+            t.frank = (int32_t) rr ; t.pad = 0 ;
+            if (i == 0 || blocks [i].group != blocks [i-1].group) prefix.push_back (0) ;
+            gprefix [i] = (i > 0 && blocks [i].group == blocks [i-1].group) ? gprefix [i-1] : (int64_t) prefix.size ( ) - 1 ;
+            prefix.push_back (prefix.back ( ) + (rr + 31) / 32) ;
+        }
+        const size_t tbytes = tasks.size ( ) * sizeof (QrPackRTask), pbytes = prefix.size ( ) * sizeof (long long) ;
+        hipError_t e = dc->ensure (&dc->d_pack, &dc->cap_pack, tbytes + pbytes, false) ;
+        if (e != hipSuccess) return e ;
+        d_tasks = (const QrPackRTask *) dc->d_pack ;
+        d_prefix = (const long long *) ((char *) dc->d_pack + tbytes) ;
+        e = hipMemcpyAsync (dc->d_pack, tasks.data ( ), tbytes, hipMemcpyHostToDevice, stream) ;
+        if (e != hipSuccess) return e ;
+        e = hipMemcpyAsync ((char *) dc->d_pack + tbytes, prefix.data ( ), pbytes, hipMemcpyHostToDevice, stream) ;
+        if (e != hipSuccess) return e ;
+        return hipStreamSynchronize (stream) ;      // the host arrays go away
+    }
+
+    bool due (int32_t group) const { return pos < blocks.size ( ) && blocks [pos].group <= group ; }
+
+    // pack and send the groups up to `group`; the stream has already been told what to wait for
+    hipError_t issue (int32_t group, hipStream_t stream)
+    {
+        while (due (group))
+        {
+            size_t end = pos ;
+            while (end < blocks.size ( ) && blocks [end].group == blocks [pos].group) end++ ;
+            const int64_t g0 = gprefix [pos] ;       // the group's counts: prefix [g0 + (pos - first of group)]
+            hipError_t e = qr_launch_pack_r (d_tasks + pos, d_prefix + g0, (int) (end - pos), prefix [g0 + (int64_t) (end - pos)], stream) ;
+            if (e != hipSuccess) return e ;
+            for (size_t i = pos ; i < end ; )
+            {
+                size_t j = i + 1 ;
+                size_t bytes = blocks [i].bytes ;
+                if (blocks [i].host == NULL) { i = j ; continue ; }
+                while (j < end && blocks [j].host != NULL && blocks [j].dev == blocks [i].dev + bytes && blocks [j].host == blocks [i].host + bytes)
+                {
+                    bytes += blocks [j].bytes ; j++ ;
+                }
+                e = hipMemcpyAsync (blocks [i].host, blocks [i].dev, bytes, hipMemcpyDeviceToHost, stream) ;
+                if (e != hipSuccess) return e ;
+                i = j ;
+            }
+            pos = end ;
+        }
+        return hipSuccess ;
+    }
+} ;
+
 // Queue the launches of the schedule in dc->lp (tasks and workgroup lists already on their way to
 // the device on the critical stream) and wait for them.
 static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, const hvec<double> &bflops,
@@ -631,6 +721,12 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, cons
             HIP_TRY (hipEventRecord (evStart, sCompute)) ;
             for (int c = 1 ; c < QR_NCLASS ; c++) HIP_TRY (hipStreamWaitEvent (cstream [c], evStart, 0)) ;    // the task upload
             size_t pi = 0, nev = 0 ;
+            // R blocks packed for the caller: fronts grouped by the rounds in which they become final
+            static int rgroup = 0 ;
+            if (rgroup == 0) { const char *e = getenv ("GPUQR_RCOPY_GROUP") ; rgroup = e ? std::max (1, atoi (e)) : 256 ; }
+            RPackOut rout ;
+            double rout_ms = 0 ; int rout_calls = 0 ;
+            HIP_TRY (rout.build (dc, fronts, nf, [&] (int64_t f) { return std::min (final_round (f), nrounds - 1) / rgroup ; }, sCopy)) ;
             // evAt [c][r]: event recorded after the last launch of class c in the latest round <= r that had one
             hvec<hipEvent_t> evAt [QR_NCLASS] ;
             for (int c = 0 ; c < QR_NCLASS ; c++) evAt [c].assign ((size_t) nrounds, (hipEvent_t) NULL) ;
@@ -744,11 +840,20 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, cons
                         HIP_TRY (pull_rows (fr, nrows, sCopy)) ;
                     }
                 }
+                // R blocks of the fronts that became final in this group of rounds
+                if (((r + 1) % rgroup == 0 || r == nrounds - 1) && rout.due (r / rgroup))
+                {
+                    const double t0 = eng_verbose ? eng_now_ms ( ) : 0 ;
+                    for (int c = 0 ; c < QR_NCLASS ; c++) if (evAt [c][r]) HIP_TRY (hipStreamWaitEvent (sCopy, evAt [c][r], 0)) ;
+                    HIP_TRY (rout.issue (r / rgroup, sCopy)) ;
+                    if (eng_verbose) { rout_ms += eng_now_ms ( ) - t0 ; rout_calls++ ; }
+                }
             }
             for (int c = 1 ; c < QR_NCLASS ; c++)
                 if (nrounds > 0 && evAt [c][nrounds-1]) HIP_TRY (hipStreamWaitEvent (sCompute, evAt [c][nrounds-1], 0)) ;
             HIP_TRY (hipEventRecord (evStop, sCompute)) ;
             ENG_TICK ("launch loop (host)") ;
+            if (eng_verbose && rout_calls > 0) fprintf (stderr, "    [engine] of which R hand-off: %d groups, %.2f ms, %d rounds\n", rout_calls, rout_ms, (int) nrounds) ;
             HIP_TRY (hipStreamSynchronize (sCompute)) ;
             HIP_TRY (hipStreamSynchronize (sApply)) ;
             if (dc->sSmall) HIP_TRY (hipStreamSynchronize (dc->sSmall)) ;
@@ -1147,6 +1252,12 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
             HIP_TRY (hipEventRecord (evStop, sCompute)) ;
             int qstate [2] = {0, 0} ;
             HIP_TRY (hipMemcpyAsync (qstate, dc->d_counters, sizeof (qstate), hipMemcpyDeviceToHost, sCompute)) ;
+            {
+                // R blocks packed for the caller: one group, behind the kernel
+                RPackOut rout ;
+                HIP_TRY (rout.build (dc, fronts, nf, [] (int64_t) { return 0 ; }, sCopy)) ;
+                HIP_TRY (rout.issue (0, sCompute)) ;
+            }
             for (int64_t f = 0 ; f < nf ; f++)
             {
                 gpuqr_front &fr = fronts [f] ;

@@ -494,6 +494,8 @@ static int factorize_impl
 
         const Long ngroups = mine ? 1 : S->numStages ;
         Long rhead = 0, chead = 0 ;
+        // With a page-locked stack the engine itself packs R and sends it (GPUQR_LATE_R: afterwards, in one copy)
+        const bool r_in_engine = num->RstackPinned && getenv ("GPUQR_LATE_R") == NULL ;
         std::vector<Long> list, FOff, SOff, ROff ;
         std::vector<PackRTask> ptasks ;
         std::vector<long long> prefix ;
@@ -566,6 +568,12 @@ static int factorize_impl
                 fr.Stair = (int64_t *) Stair.data ( ) + Rp [f] ;
                 fr.gpuF = F0 + FOff [k] ;
                 fr.cpuR = NULL ;                    // R is packed on the device, see below
+                if (r_in_engine)
+                {
+                    // the engine packs the block once the front is final and sends it while the rest runs
+                    fr.gpuRpack = (double *) dR.p + ROff [k] ;
+                    fr.cpuRpack = num->Rstack + rhead + ROff [k] ;
+                }
                 fr.is_sparse = 1 ;
                 fr.nc = (int32_t) (Childp [f+1] - Childp [f]) ;
                 fr.Scount = S_count (f) ;
@@ -630,10 +638,11 @@ static int factorize_impl
             uint64_t plan_key = 0 ;
             if (ngroups == 1 && nlimbo == 0 && getenv ("GPUQR_NO_PLAN_CACHE") == NULL)
             {
-                const uint64_t parts [6] = {S->uid, (uint64_t) (uintptr_t) dF.p, (uint64_t) (uintptr_t) dS.p,
-                    (uint64_t) (uintptr_t) NC.d_Rimap, (uint64_t) (uintptr_t) NC.d_Rjmap, (uint64_t) numFronts} ;
+                const uint64_t parts [7] = {S->uid, (uint64_t) (uintptr_t) dF.p, (uint64_t) (uintptr_t) dS.p,
+                    (uint64_t) (uintptr_t) NC.d_Rimap, (uint64_t) (uintptr_t) NC.d_Rjmap, (uint64_t) numFronts,
+                    r_in_engine ? (uint64_t) (uintptr_t) dR.p : 0} ;
                 plan_key = 1469598103934665603ull ;
-                for (int i = 0 ; i < 6 ; i++) for (int b = 0 ; b < 8 ; b++) { plan_key ^= (parts [i] >> (8*b)) & 0xff ; plan_key *= 1099511628211ull ; }
+                for (int i = 0 ; i < 7 ; i++) for (int b = 0 ; b < 8 ; b++) { plan_key ^= (parts [i] >> (8*b)) & 0xff ; plan_key *= 1099511628211ull ; }
                 if (mine) for (Long f = 0 ; f < nf ; f++) { plan_key ^= (uint64_t) (mine [f] != 0) ; plan_key *= 1099511628211ull ; }
                 plan_key |= 1 ;
             }
@@ -648,6 +657,12 @@ static int factorize_impl
             used_dev.clear ( ) ;
 
             // ---- R: packed on the device, one copy onto the stack ---------------------------------
+            if (r_in_engine)
+            {
+                for (Long k = 0 ; k < numFronts ; k++) num->Rblock [list [k]] = rhead + ROff [k] ;
+                rhead += rsum ;
+            }
+            else
             {
                 ptasks.assign ((size_t) numFronts, PackRTask ( )) ;
                 prefix.assign ((size_t) numFronts + 1, 0) ;
@@ -675,7 +690,8 @@ static int factorize_impl
                     HIPCHK (copy_to_pageable (num->Rstack + rhead, dR.p, (size_t) rsum * sizeof (double), WS.hBounce)) ;
                 }
                 rhead += rsum ;
-
+            }
+            {
                 // contribution blocks that leave the group: compact cm-by-cn, zero below the diagonal
                 for (Long k = 0 ; k < numFronts ; k++)
                 {

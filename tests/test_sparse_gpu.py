@@ -153,6 +153,27 @@ def test_pageable_r_stack_fallback(monkeypatch):
     assert (r0.R != r1.R).nnz == 0
 
 
+@pytest.mark.parametrize("grid,leaf,mem,mode", [((30, 30), 4, 2**34, 0), ((10, 10, 10), 2, 2**34, 0),
+                                                ((30, 30), 4, 2**22, 0), ((30, 30), 4, 2**34, 1)])
+def test_r_packed_inside_the_engine_equals_r_packed_afterwards(monkeypatch, grid, leaf, mem, mode):
+    """R blocks packed and sent by the engine while later fronts still run (page-locked stack) are
+    bit for bit the blocks packed in one pass after the engine returned; also when the tree is cut
+    into stages and when the work-queue kernel runs the schedule."""
+    from suitesparse_amd import _lib
+    A = problems.stacked_ls(grid)
+    sym = spqr.analyze(A, problems.nested_dissection(grid, leaf=leaf), relax=20, gpuMemorySize=mem)
+    _lib.lib().gpuqr_set_mode(mode)
+    try:
+        r0 = spqr.factorize(sym, A)
+        r0b = spqr.factorize(sym, A)
+        monkeypatch.setenv("GPUQR_LATE_R", "1")
+        r1 = spqr.factorize(sym, A)
+    finally:
+        _lib.lib().gpuqr_set_mode(0)
+    assert (r0.R != r1.R).nnz == 0 and (r0b.R != r1.R).nnz == 0
+    assert r0.R.nnz == r1.R.nnz
+
+
 def test_repeated_factorizations_reuse_the_schedule_and_follow_the_values(monkeypatch):
     """A second factorization on the same symbolic object replays the engine's schedule; it must
     track new values, survive other engine calls in between, and agree with the uncached path."""
