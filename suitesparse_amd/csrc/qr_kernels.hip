@@ -79,15 +79,36 @@ __device__ __forceinline__ d2 pair_exchange (d2 v)
     return o ;
 }
 
+// The same exchange when the two lanes are 16 apart (neighbouring rows of 16 lanes): the odd rows
+// of the first register trade places with the even rows of the second.  Its own inverse too.
+__device__ __forceinline__ d2 pair_exchange16 (d2 v)
+{
+    auto lo = __builtin_amdgcn_permlane16_swap ((unsigned) __double2loint (v.x), (unsigned) __double2loint (v.y), false, false) ;
+    auto hi = __builtin_amdgcn_permlane16_swap ((unsigned) __double2hiint (v.x), (unsigned) __double2hiint (v.y), false, false) ;
+    d2 o ;
+    o.x = __hiloint2double ((int) hi [0], (int) lo [0]) ;
+    o.y = __hiloint2double ((int) hi [1], (int) lo [1]) ;
+    return o ;
+}
+
+template <int RG> __device__ __forceinline__ d2 pair_exchange_rg (d2 v)
+{
+    if constexpr (RG == 8) return pair_exchange (v) ; else return pair_exchange16 (v) ;
+}
+
 // -----------------------------------------------------------------------------
 // factorize_panel
 // -----------------------------------------------------------------------------
 //
-// Each of the 4 waves owns 8 of the 32 panel columns.  Lane l of a wave stands
-// for column cl = l/8 of the wave and row group rg = l%8, and keeps rows rg,
-// rg+8, ... of its column in registers (RPT of them).  A sum over the rows of
-// one column is then a sum over 8 neighbouring lanes: three DPP steps, no LDS
-// and no barrier.  Per column k:
+// The rows of a column are dealt to RG lanes (RG = 8 or 16 row groups), so a wave
+// owns 64/RG of the 32 panel columns and the workgroup has 32*RG threads (4 or 8
+// waves).  Lane l of a wave stands for column cl = l/RG of the wave and row group
+// rg = l%RG, and keeps rows rg, rg+RG, ... of its column in registers (RPT of them).
+// A sum over the rows of one column is then a sum over RG neighbouring lanes: three
+// or four DPP steps, no LDS and no barrier.  The chain of dependent operations per
+// column grows with RPT (a lone wave issues a double precision operation only every
+// 8 to 10 cycles), which is why the stand-alone kernels use RG = 16: half the
+// registers per lane, half the chain.  Per column k:
 //   every lane reads the normalised Householder vector v_k (v_kk = 1, zeros
 //   above) from LDS, forms its share of v_k'a_c, reduces it over its 8 lanes,
 //   and updates its column: a_c -= tau (v_k'a_c) v_k;
@@ -122,56 +143,74 @@ template <int CTRL> __device__ __forceinline__ double dpp_move (double x)
     return __hiloint2double (hi, lo) ;
 }
 
-// sum over each group of 8 neighbouring lanes, result in all 8
-__device__ __forceinline__ double sum8 (double x)
+// sum over each group of RG neighbouring lanes, result in all of them
+template <int RG> __device__ __forceinline__ double sum_rows (double x)
 {
+#ifdef FACT_NO_REDUCE
+    return x ;
+#endif
     x += dpp_move<0xB1> (x) ;       // quad_perm [1,0,3,2]
     x += dpp_move<0x4E> (x) ;       // quad_perm [2,3,0,1]
     x += dpp_move<0x141> (x) ;      // row_half_mirror: lane i <-> 7-i of each 8
+    if constexpr (RG == 16) x += dpp_move<0x140> (x) ;     // row_mirror: lane i <-> 15-i of each 16
     return x ;
 }
 
-// Column kc of T, by the lower 32 lanes of one wave (lane j: row j).  Z(i,kc) = 0 for i >= kc and
-// T(j,i) = 0 for i < j (both arrays start as zeros), so the sums need no masks.
+// Column kc of T, by one wave: lane l works on row l%32 and takes every other group of four
+// terms (l/32 says which), the two halves of the wave are added at the end.  Z(i,kc) = 0 for
+// i >= kc and T(j,i) = 0 for i < j (both arrays start as zeros), so the sums need no masks and
+// may run past kc to the end of a group.  This runs beside the Householder step of its wave and
+// must not take longer than the reflector of the owning wave, or it becomes the critical path.
 __device__ __forceinline__ void t_column (FactorizeLds &L, const int kc, const int lane)
 {
-    if (lane < 32)
+    const int j = lane & 31, h = lane >> 5 ;
+    double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0 ;
+    #pragma unroll 2
+    for (int i = 4*h ; i < kc ; i += 8)
     {
-        double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0 ;
-        for (int i = 0 ; i < kc ; i += 4)
-        {
-            acc0 += L.T [lane][i]   * L.Z [i][kc] ;
-            acc1 += L.T [lane][i+1] * L.Z [i+1][kc] ;
-            acc2 += L.T [lane][i+2] * L.Z [i+2][kc] ;
-            acc3 += L.T [lane][i+3] * L.Z [i+3][kc] ;
-        }
-        L.T [lane][kc] = (lane < kc) ? ((acc0 + acc1) + (acc2 + acc3)) : ((lane == kc) ? L.tau [kc] : 0.0) ;
+        acc0 += L.T [j][i]   * L.Z [i][kc] ;
+        acc1 += L.T [j][i+1] * L.Z [i+1][kc] ;
+        acc2 += L.T [j][i+2] * L.Z [i+2][kc] ;
+        acc3 += L.T [j][i+3] * L.Z [i+3][kc] ;
     }
+    const double x = (acc0 + acc1) + (acc2 + acc3) ;
+    // lanes 32..63 of the first register trade places with lanes 0..31 of the second
+    auto lo = __builtin_amdgcn_permlane32_swap ((unsigned) __double2loint (x), (unsigned) __double2loint (x), false, false) ;
+    auto hi = __builtin_amdgcn_permlane32_swap ((unsigned) __double2hiint (x), (unsigned) __double2hiint (x), false, false) ;
+    const double sum = __hiloint2double ((int) hi [0], (int) lo [0]) + __hiloint2double ((int) hi [1], (int) lo [1]) ;
+    if (lane < 32) L.T [j][kc] = (j < kc) ? sum : ((j == kc) ? L.tau [kc] : 0.0) ;
 }
 
 // The 8 lanes of column k1 (all of them active, nobody else) make its reflector and publish it:
 // vb[r] = 0 above row k1, 1 at k1, a_r/v1 below, for the rows of slots >= I0; returns R(k1,k1).
-template <int RPT>
+template <int RPT, int RG>
 __device__ __forceinline__ double make_reflector
 (
     const double (&a) [RPT], FactorizeLds &L, const int k1, const int i0, const int rg
 )
 {
-    double part = 0, x1 = 0 ;
+    double part = 0, part1 = 0, x1 = 0 ;
     #pragma unroll
     for (int i = 0 ; i < RPT ; i++)
     {
-        const int r = rg + 8*i ;
+        const int r = rg + RG*i ;
         const double x = a [i] ;
-        if (r > k1) part += x*x ;
+        if (r > k1) { if (i & 1) part1 += x*x ; else part += x*x ; }
         else if (r == k1) x1 = x ;
     }
-    const double sigma = sum8 (part) ;
-    x1 = sum8 (x1) ;                // one lane holds it, the others add zeros
-    // The scalar part sits on the critical path of every column, so it is built from the
-    // hardware reciprocal and reciprocal square root seeds with two Newton steps each (a
-    // dozen dependent operations) instead of the library square root and two divisions.
+    const double sigma = sum_rows<RG> (part + part1) ;
+    x1 = sum_rows<RG> (x1) ;        // one lane holds it, the others add zeros
+    // The scalar part sits on the critical path of every column (a lone wave issues a dependent
+    // double precision operation only every 16 cycles or so), so it is built from the hardware
+    // reciprocal and reciprocal square root seeds with two Newton steps each, and arranged so that
+    // only one reciprocal depends on the square root: with q = |x1| + s (no cancellation),
+    //   x1 <= 0:  v1 = x1 - s = -q,          1/v1 = -1/q,       tau = -v1/s = q/s
+    //   x1 >  0:  v1 = -sigma/(x1 + s) = -sigma/q,  1/v1 = -q/sigma,  tau = sigma/(q s)
+    // and 1/sigma is refined next to 1/sqrt(n2), off the chain.
     double s, tau, inv ;
+#ifdef FACT_NO_SCALAR
+    if (true) { s = x1 ; tau = 0.5 ; inv = sigma ; } else
+#endif
     if (sigma <= HOUSE_EPS)
     {
         s = x1 ; tau = 0 ; inv = 0 ;
@@ -180,56 +219,61 @@ __device__ __forceinline__ double make_reflector
     {
         const double n2 = fma (x1, x1, sigma) ;
         double y = __builtin_amdgcn_rsq (n2) ;                  // ~ 1/s
+        double rs = __builtin_amdgcn_rcp (sigma) ;              // ~ 1/sigma
         y = fma (0.5 * y, fma (-n2 * y, y, 1.0), y) ;
+        rs = fma (rs, fma (-sigma, rs, 1.0), rs) ;
         y = fma (0.5 * y, fma (-n2 * y, y, 1.0), y) ;
+        rs = fma (rs, fma (-sigma, rs, 1.0), rs) ;
         s = n2 * y ;
         s = fma (fma (-s, s, n2), 0.5 * y, s) ;                 // s = sqrt (n2)
-        const double q = x1 + s ;                               // used when x1 > 0: no cancellation
+        const double q = fabs (x1) + s ;
         double rq = __builtin_amdgcn_rcp (q) ;
+        const double qs = -q * rs ;                             // 1/v1 when x1 > 0
         rq = fma (rq, fma (-q, rq, 1.0), rq) ;
         rq = fma (rq, fma (-q, rq, 1.0), rq) ;
-        const double v1 = (x1 <= 0) ? (x1 - s) : (-sigma * rq) ;
-        tau = -v1 * y ;
-        inv = __builtin_amdgcn_rcp (v1) ;
-        inv = fma (inv, fma (-v1, inv, 1.0), inv) ;
-        inv = fma (inv, fma (-v1, inv, 1.0), inv) ;
+        inv = (x1 <= 0) ? -rq : qs ;
+        tau = (x1 <= 0) ? (q * y) : (sigma * rq * y) ;
     }
     double *vb = L.vbuf [k1 & 1] ;
     #pragma unroll
     for (int i = 0 ; i < RPT ; i++)
     {
-        const int r = rg + 8*i ;
+        const int r = rg + RG*i ;
         if (i >= i0) vb [r] = (r > k1) ? a [i] * inv : ((r == k1) ? 1.0 : 0.0) ;
     }
     if (rg == 0) L.tau [k1] = tau ;
     return s ;
 }
 
-// The 8 Householder steps k = 8*IK .. 8*IK+7.  With rows dealt to lanes as
-// r = rg + 8*i, the register slot of the pivot row (i = IK) is a compile-time
+// The RG Householder steps k = RG*IK .. RG*IK+RG-1.  With rows dealt to lanes as
+// r = rg + RG*i, the register slot of the pivot row (i = IK) is a compile-time
 // constant inside this function: slots i < IK lie entirely above the pivot row
 // and are skipped (v is zero there).
-template <int RPT, int IK>
+template <int RPT, int RG, int IK>
 __device__ __forceinline__ void house_steps
 (
     double (&a) [RPT], double &s_cur, FactorizeLds &L, const int kmax, const int rg, const int c,
     const int wave, const int lane
 )
 {
-    if constexpr (IK < RPT)
+    constexpr int CPW = 64 / RG ;                       // columns per wave
+    constexpr int NW = 32 / CPW ;                       // waves
+    if constexpr (IK < RPT && IK * RG < 32)
     {
-        for (int rgk = 0 ; rgk < 8 ; rgk++)
+        for (int rgk = 0 ; rgk < RG ; rgk++)
         {
-            const int k = 8*IK + rgk ;
+            const int k = RG*IK + rgk ;
             if (k >= kmax) break ;
             const int k1 = k + 1 ;
-            const int own1 = (k1 >> 3) & 3 ;            // the wave that owns column k+1: the critical one
-            if (k > 0 && wave == ((own1 + 2) & 3)) t_column (L, k - 1, lane) ;
+            const int own1 = (k1 / CPW) & (NW - 1) ;    // the wave that owns column k+1: the critical one
+#ifndef FACT_NO_T
+            if (k > 0 && wave == ((own1 + NW/2) & (NW - 1))) t_column (L, k - 1, lane) ;
+#endif
 
             const double *vb = L.vbuf [k & 1] ;
             double v [RPT] ;
             #pragma unroll
-            for (int i = IK ; i < RPT ; i++) v [i] = vb [rg + 8*i] ;
+            for (int i = IK ; i < RPT ; i++) v [i] = vb [rg + RG*i] ;
             const double tau = L.tau [k] ;
 
             double d0 = 0, d1 = 0 ;
@@ -238,7 +282,7 @@ __device__ __forceinline__ void house_steps
             {
                 if ((i - IK) & 1) d1 += v [i] * a [i] ; else d0 += v [i] * a [i] ;
             }
-            const double z = -tau * sum8 (d0 + d1) ;
+            const double z = -tau * sum_rows<RG> (d0 + d1) ;
 
             if (c > k)
             {
@@ -262,7 +306,7 @@ __device__ __forceinline__ void house_steps
 
             if (wave == own1 && k1 < kmax)
             {
-                if (c == k1) s_cur = make_reflector<RPT> (a, L, k1, (rgk == 7) ? IK + 1 : IK, rg) ;
+                if (c == k1) s_cur = make_reflector<RPT, RG> (a, L, k1, (rgk == RG - 1) ? IK + 1 : IK, rg) ;
             }
             __syncthreads ( ) ;
         }
@@ -277,9 +321,10 @@ __device__ unsigned long long g_fact_stats [8] ;
 #define FACT_TICK(i)
 #endif
 
-template <int RPT>
+template <int RPT, int RG>
 __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *smem)
 {
+    constexpr int NT = 32 * RG ;                        // threads of the workgroup
 #ifdef FACT_STATS
     unsigned long long tick = __builtin_amdgcn_s_memtime ( ) ;
 #endif
@@ -287,18 +332,18 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
     const int tid = threadIdx.x ;
     const int lane = tid & 63 ;
     const int wave = __builtin_amdgcn_readfirstlane (tid >> 6) ;    // a scalar: branches on it are uniform
-    const int rg = lane & 7 ;
-    const int c = 8*wave + (lane >> 3) ;
+    const int rg = lane & (RG - 1) ;
+    const int c = (64 / RG) * wave + lane / RG ;
     const int K = t.K, w = t.w, ld = t.ld ;
     const int kmax = (K < w) ? K : w ;
     gdouble *F = (gdouble *) t.F ;
     gdouble *VT = (gdouble *) t.VT ;
 
-    build_rowmap (t, L.rowmap, 8*RPT) ;
-    for (int i = tid ; i < 2*32*33 ; i += QR_THREADS) (&L.Z[0][0]) [i] = 0 ;     // Z and T
+    build_rowmap (t, L.rowmap, RG*RPT) ;
+    for (int i = tid ; i < 2*32*33 ; i += NT) (&L.Z[0][0]) [i] = 0 ;             // Z and T
     __syncthreads ( ) ;
 
-    // Load with 16 bytes per lane: the lanes of columns c and c^1 (8 lanes apart) each fetch both
+    // Load with 16 bytes per lane: the lanes of columns c and c^1 (RG lanes apart) each fetch both
     // columns of one of two rows, then trade one element (see pair_exchange).
     double a [RPT] ;
     const int cb = c & ~1 ;                                     // first column of the lane's pair
@@ -307,7 +352,7 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
     #pragma unroll
     for (int i = 0 ; i < RPT ; i += 2)
     {
-        const int r = rg + 8 * (i + (c & 1)) ;                  // even column: first row of the two
+        const int r = rg + RG * (i + (c & 1)) ;                 // even column: first row of the two
         d2 v = {0.0, 0.0} ;
         if (r < K && pair0)
         {
@@ -320,21 +365,21 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
     for (int i = 0 ; i < RPT ; i += 2)
     {
         d2 v = {a [i], a [i+1]} ;
-        v = pair_exchange (v) ;
+        v = pair_exchange_rg<RG> (v) ;
         a [i] = (c < w) ? v.x : 0.0 ;
         a [i+1] = (c < w) ? v.y : 0.0 ;
     }
 
     double s_cur = 0 ;
-    if (wave == 0 && c == 0) s_cur = make_reflector<RPT> (a, L, 0, 0, rg) ;
+    if (wave == 0 && c == 0) s_cur = make_reflector<RPT, RG> (a, L, 0, 0, rg) ;
     __syncthreads ( ) ;
 
     FACT_TICK (0) ;
-    house_steps<RPT, 0> (a, s_cur, L, kmax, rg, c, wave, lane) ;
+    house_steps<RPT, RG, 0> (a, s_cur, L, kmax, rg, c, wave, lane) ;
     FACT_TICK (1) ;
-    house_steps<RPT, 1> (a, s_cur, L, kmax, rg, c, wave, lane) ;
-    house_steps<RPT, 2> (a, s_cur, L, kmax, rg, c, wave, lane) ;
-    house_steps<RPT, 3> (a, s_cur, L, kmax, rg, c, wave, lane) ;
+    house_steps<RPT, RG, 1> (a, s_cur, L, kmax, rg, c, wave, lane) ;
+    house_steps<RPT, RG, 2> (a, s_cur, L, kmax, rg, c, wave, lane) ;
+    house_steps<RPT, RG, 3> (a, s_cur, L, kmax, rg, c, wave, lane) ;
     FACT_TICK (2) ;
 
     // ---- write back R (zeros below the diagonal), V2 in place, V1 to the VT tile ----
@@ -345,7 +390,7 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
         #pragma unroll
         for (int e = 0 ; e < 2 ; e++)
         {
-            const int r = rg + 8 * (i + e) ;
+            const int r = rg + RG * (i + e) ;
             double val = a [i + e] ;
             if (r < w)
             {
@@ -354,8 +399,8 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
             }
             o [e] = val ;
         }
-        o = pair_exchange (o) ;                                 // back to (one row, two columns)
-        const int r = rg + 8 * (i + (c & 1)) ;
+        o = pair_exchange_rg<RG> (o) ;                          // back to (one row, two columns)
+        const int r = rg + RG * (i + (c & 1)) ;
         if (r < K && pair0)
         {
             gdouble *p = F + (size_t) L.rowmap [r] * ld + t.col0 + cb ;
@@ -369,7 +414,7 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
     {
         if (wave == 0) t_column (L, kmax - 1, lane) ;
         __syncthreads ( ) ;
-        for (int idx = tid ; idx < 32*32 ; idx += QR_THREADS)
+        for (int idx = tid ; idx < 32*32 ; idx += NT)
         {
             const int r = idx >> 5, cc = idx & 31 ;
             if (cc >= r && r < w && cc < w) VT [r*32 + cc] = L.T [r][cc] ;
@@ -746,11 +791,15 @@ extern "C" hipError_t qr_launch_pack_r (const QrPackRTask *d_tasks, const long l
 // kernels: one per task kind and row tier, so each gets its own register budget
 // -----------------------------------------------------------------------------
 
-template <int RPT>
-__global__ void __launch_bounds__ (QR_THREADS, 2) k_factorize (const QrTask *tasks, const QrRef *refs)
+// The stand-alone panel kernels run 16 row groups (512 threads, RPT = rows / 16), except for the
+// 32-row tier: there the chain per column is short already and the fourth reduction step costs
+// more than the halved row count saves, so it keeps 8 row groups (256 threads).
+#define QR_FACT_THREADS 512
+template <int RPT, int RG>
+__global__ void __launch_bounds__ (32 * RG, 2) k_factorize (const QrTask *tasks, const QrRef *refs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem [] ;
-    factorize_panel<RPT> (tasks [refs [blockIdx.x].task].u.panel, smem) ;
+    factorize_panel<RPT, RG> (tasks [refs [blockIdx.x].task].u.panel, smem) ;
 }
 
 template <int MT>
@@ -764,16 +813,17 @@ __global__ void __launch_bounds__ (QR_THREADS, 2) k_apply (const QrTask *tasks, 
 // All row tiers in one launch: the panel tasks of a round are few and latency-bound, so four
 // launches in a row (one per tier) cost the sum of four latencies where one launch costs the
 // longest.  The same holds for the three small tiers of the update.
-__global__ void __launch_bounds__ (QR_THREADS, 2) k_factorize_all (const QrTask *tasks, const QrRef *refs)
+__global__ void __launch_bounds__ (QR_FACT_THREADS, 2) k_factorize_all (const QrTask *tasks, const QrRef *refs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem [] ;
     const QrTask &t = tasks [refs [blockIdx.x].task] ;
     switch (__builtin_amdgcn_readfirstlane (t.tier))
     {
-        case 0:  factorize_panel<4>  (t.u.panel, smem) ; break ;
-        case 1:  factorize_panel<8>  (t.u.panel, smem) ; break ;
-        case 2:  factorize_panel<16> (t.u.panel, smem) ; break ;
-        default: factorize_panel<32> (t.u.panel, smem) ; break ;
+        // (the upper four waves leave at once: a barrier only counts the waves still running)
+        case 0:  if (threadIdx.x < 256) factorize_panel<4, 8> (t.u.panel, smem) ; break ;
+        case 1:  factorize_panel<4, 16>  (t.u.panel, smem) ; break ;
+        case 2:  factorize_panel<8, 16>  (t.u.panel, smem) ; break ;
+        default: factorize_panel<16, 16> (t.u.panel, smem) ; break ;
     }
 }
 
@@ -868,7 +918,7 @@ template <int RPT>
 __device__ __attribute__((noinline)) void pq_factorize (const QrPanelTask &t)
 {
     extern __shared__ __attribute__((aligned(16))) char smem [] ;
-    factorize_panel<RPT> (*uni_ptr (&t), smem) ;
+    factorize_panel<RPT, 8> (*uni_ptr (&t), smem) ;        // the queue kernel's workgroups have 256 threads
 }
 template <int MT>
 __device__ __attribute__((noinline)) void pq_apply (const QrPanelTask &t, const int blk)
@@ -1014,20 +1064,20 @@ extern "C" hipError_t qr_launch_persistent (const QrTask *d_tasks, const QrQueue
 extern "C" hipError_t qr_launch_tasks (int kid, const QrTask *d_tasks, const QrRef *d_refs, int nrefs, hipStream_t stream)
 {
     if (nrefs <= 0) return hipSuccess ;
-    const dim3 grid (nrefs), block (QR_THREADS) ;
+    const dim3 grid (nrefs), block (QR_THREADS), fblock (QR_FACT_THREADS) ;
     const size_t lds = kernel_lds_bytes (kid) ;
     switch (kid)
     {
-        case 0: hipLaunchKernelGGL (k_factorize<4>,  grid, block, lds, stream, d_tasks, d_refs) ; break ;
-        case 1: hipLaunchKernelGGL (k_factorize<8>,  grid, block, lds, stream, d_tasks, d_refs) ; break ;
-        case 2: hipLaunchKernelGGL (k_factorize<16>, grid, block, lds, stream, d_tasks, d_refs) ; break ;
-        case 3: hipLaunchKernelGGL (k_factorize<32>, grid, block, lds, stream, d_tasks, d_refs) ; break ;
+        case 0: hipLaunchKernelGGL ((k_factorize<4, 8>),   grid, block,  lds, stream, d_tasks, d_refs) ; break ;
+        case 1: hipLaunchKernelGGL ((k_factorize<4, 16>),  grid, fblock, lds, stream, d_tasks, d_refs) ; break ;
+        case 2: hipLaunchKernelGGL ((k_factorize<8, 16>),  grid, fblock, lds, stream, d_tasks, d_refs) ; break ;
+        case 3: hipLaunchKernelGGL ((k_factorize<16, 16>), grid, fblock, lds, stream, d_tasks, d_refs) ; break ;
         case 4: hipLaunchKernelGGL (k_apply<2>,      grid, block, lds, stream, d_tasks, d_refs) ; break ;
         case 5: hipLaunchKernelGGL (k_apply<4>,      grid, block, lds, stream, d_tasks, d_refs) ; break ;
         case 6: hipLaunchKernelGGL (k_apply<8>,      grid, block, lds, stream, d_tasks, d_refs) ; break ;
         case 7: hipLaunchKernelGGL (k_apply<16>,     grid, block, lds, stream, d_tasks, d_refs) ; break ;
         case 8: hipLaunchKernelGGL (k_assemble,      grid, block, lds, stream, d_tasks, d_refs) ; break ;
-        case 9:  hipLaunchKernelGGL (k_factorize_all, grid, block, lds, stream, d_tasks, d_refs) ; break ;   // tiers 0..3
+        case 9:  hipLaunchKernelGGL (k_factorize_all, grid, fblock, lds, stream, d_tasks, d_refs) ; break ;  // tiers 0..3
         case 10: hipLaunchKernelGGL (k_apply_small,   grid, block, lds, stream, d_tasks, d_refs) ; break ;   // tiers 0..2
         case 11: hipLaunchKernelGGL (k_apply_all,     grid, block, lds, stream, d_tasks, d_refs) ; break ;   // tiers 0..3
         default: return hipErrorInvalidValue ;

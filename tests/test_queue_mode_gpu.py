@@ -32,7 +32,19 @@ def _dense(mats):
     return [np.array(f.cpuR) for f in fronts], stats
 
 
-def test_dense_batch_bitwise_equal(queue_mode):
+# The queue kernel factorizes panels with 8 row groups per column (256-thread workgroups), the
+# stand-alone panel kernels with 16: the sums over a column associate differently, so the two
+# modes agree to rounding, not bit for bit.  Tolerance: 1e-12 of the largest entry of R.
+def _same_to_rounding(a, b, tol=1e-12):
+    a = np.asarray(a) ; b = np.asarray(b)
+    return a.shape == b.shape and (a.size == 0 or np.abs(a - b).max() <= tol * max(1.0, np.abs(a).max()))
+
+
+def _same_sparse_to_rounding(A, B, tol=1e-12):
+    return A.shape == B.shape and (A.nnz == 0 or abs(A - B).max() <= tol * max(1.0, abs(A).max()))
+
+
+def test_dense_batch_equal_to_rounding(queue_mode):
     rng = np.random.default_rng(11)
     shapes = [(1, 1), (40, 70), (96, 32), (300, 100), (257, 257), (1024, 384), (700, 900), (33, 31)]
     mats = [rng.standard_normal((m, n)) for m, n in shapes]
@@ -43,11 +55,11 @@ def test_dense_batch_bitwise_equal(queue_mode):
     assert s1.numLaunches == 1 and s0.numLaunches > 1
     assert s0.flopsActual == s1.flopsActual
     for a, b in zip(R0, R1):
-        assert np.array_equal(a, b)
+        assert _same_to_rounding(a, b)
 
 
 @pytest.mark.parametrize("grid,leaf", [((40, 40), 4), ((9, 9, 9), 2)])
-def test_sparse_bitwise_equal(queue_mode, grid, leaf):
+def test_sparse_equal_to_rounding(queue_mode, grid, leaf):
     A = problems.stacked_ls(grid)
     sym = spqr.analyze(A, problems.nested_dissection(grid, leaf=leaf), relax=20, gpuMemorySize=2**34)
     queue_mode(0)
@@ -55,7 +67,7 @@ def test_sparse_bitwise_equal(queue_mode, grid, leaf):
     queue_mode(1)
     r1 = spqr.factorize(sym, A)
     assert r0.rank == r1.rank == sym.n
-    assert (r0.R != r1.R).nnz == 0
+    assert _same_sparse_to_rounding(r0.R, r1.R)
 
 
 def test_staged_sparse_in_queue_mode(queue_mode):
@@ -68,7 +80,7 @@ def test_staged_sparse_in_queue_mode(queue_mode):
     assert sym.numStages > 1
     res = spqr.factorize(sym, A)
     assert res.numStagesRun == sym.numStages
-    assert (one.R != res.R).nnz == 0
+    assert _same_sparse_to_rounding(one.R, res.R)
 
 
 def test_auto_mode_picks_queue_for_a_chain_and_launches_for_a_batch(queue_mode):
@@ -83,5 +95,5 @@ def test_auto_mode_picks_queue_for_a_chain_and_launches_for_a_batch(queue_mode):
     Rb2, sb2 = _dense(batch)
     assert sc2.numLaunches == 1 and sc0.numLaunches > 1
     assert sb2.numLaunches == sb0.numLaunches
-    assert all(np.array_equal(a, b) for a, b in zip(Rc0, Rc2))
-    assert all(np.array_equal(a, b) for a, b in zip(Rb0, Rb2))
+    assert all(_same_to_rounding(a, b) for a, b in zip(Rc0, Rc2))      # the queue ran the chain
+    assert all(np.array_equal(a, b) for a, b in zip(Rb0, Rb2))         # launches both times
