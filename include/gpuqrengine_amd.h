@@ -124,7 +124,10 @@ size_t gpuqr_max_queue_size (size_t gpuMemorySize);
  * every call made with it describes that one problem: the engine then builds and uploads its schedule
  * once and replays it while no call with another key (or none) has intervened on the device.  No
  * counterpart in the reference, which rebuilds its Scheduler on every call
- * (GPUQREngine/Source/GPUQREngine_Internal.cpp:34-51).  plan_key = 0 behaves as gpuqr_factor_sparse. */
+ * (GPUQREngine/Source/GPUQREngine_Internal.cpp:34-51).  plan_key = 0 behaves as gpuqr_factor_sparse:
+ * the engine then derives a key itself from the front descriptors and the staircase contents (a
+ * 64-bit fingerprint, a few ms for a million fronts' worth), so an unchanged description is
+ * replayed all the same; GPUQR_NO_PLAN_CACHE in the environment turns that off. */
 int gpuqr_factor_sparse_keyed (size_t gpuMemorySize, gpuqr_front *fronts, int64_t numFronts,
                                const int64_t *Parent, const int64_t *Childp, const int64_t *Child,
                                gpuqr_stats *stats, uint64_t plan_key);

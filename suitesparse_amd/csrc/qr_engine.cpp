@@ -444,6 +444,7 @@ struct LaunchPlan
     hvec<int64_t> rptr ;            // first workgroup of every (round, slot) bucket
     hvec<int32_t> bdep ;            // per bucket and class: latest round depended on
     hvec<int32_t> done_last ;       // per front and class: latest round used
+    hvec<double> bflops, bbytes ;   // per bucket: flops and algorithmic bytes of its tasks
     int32_t nrounds = 0 ;
     int64_t nbuckets = 0, ntasks = 0, nrefs = 0 ;
     int64_t flops = 0 ;
@@ -657,11 +658,12 @@ struct RPackOut
 
 // Queue the launches of the schedule in dc->lp (tasks and workgroup lists already on their way to
 // the device on the critical stream) and wait for them.
-static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, const hvec<double> &bflops,
-    const hvec<double> &bbytes, gpuqr_stats *stats, const bool eng_verbose, double &eng_tlast)
+static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats,
+    const bool eng_verbose, double &eng_tlast)
 {
     int code = GPUQR_SUCCESS ;
     const LaunchPlan &lp = dc->lp ;
+    const hvec<double> &bflops = lp.bflops, &bbytes = lp.bbytes ;
     const hvec<int64_t> &rptr = lp.rptr ;
     const hvec<int32_t> &bdep = lp.bdep, &done_last = lp.done_last ;
     const int32_t nrounds = lp.nrounds ;
@@ -900,6 +902,32 @@ cleanup:
     return code ;
 }
 
+// Fingerprint of everything the schedule and the task descriptors are built from: the front
+// descriptors as they stand (shapes, flags, every pointer) and the contents of the staircases.
+// Two calls with the same fingerprint differ at most in the values stored behind the pointers.
+static uint64_t problem_fingerprint (const gpuqr_front *fronts, int64_t nf)
+{
+    uint64_t h = 0x243F6A8885A308D3ull ^ (uint64_t) nf ;
+    auto mix = [&h] (const void *p, size_t bytes)
+    {
+        const unsigned char *b = (const unsigned char *) p ;
+        size_t i = 0 ;
+        for ( ; i + 8 <= bytes ; i += 8)
+        {
+            uint64_t w ; memcpy (&w, b + i, 8) ;
+            h = (h ^ w) * 0x9E3779B97F4A7C15ull ; h ^= h >> 29 ;
+        }
+        uint64_t w = 0 ;
+        if (i < bytes) { memcpy (&w, b + i, bytes - i) ; h = (h ^ w) * 0x9E3779B97F4A7C15ull ; h ^= h >> 29 ; }
+    } ;
+    for (int64_t f = 0 ; f < nf ; f++)
+    {
+        mix (&fronts [f], sizeof (gpuqr_front)) ;
+        if (fronts [f].Stair != NULL && fronts [f].fn > 0) mix (fronts [f].Stair, (size_t) fronts [f].fn * sizeof (int64_t)) ;
+    }
+    return h | 1 ;
+}
+
 static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint64_t plan_key)
 {
     const char *eng_env = getenv ("GPUQR_VERBOSE") ;
@@ -921,14 +949,21 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
     if (!dc) return GPUQR_GPUERROR ;
     LaunchPlan &lp = dc->lp ;
 
+    // Without a key from the caller the engine makes its own from the problem description, so that
+    // a repeated call (same shapes, staircases and buffers, new values) skips planning, sorting and
+    // the upload of the tasks just the same.
+    static int auto_key = -1 ;
+    if (auto_key < 0) auto_key = (getenv ("GPUQR_NO_PLAN_CACHE") == NULL) ? 1 : 0 ;
+    if (plan_key == 0 && auto_key && engine_mode ( ) == 0)
+    {
+        plan_key = problem_fingerprint (fronts, nf) ;
+        ENG_TICK ("fingerprint") ;
+    }
+
     // The caller vouches, by passing the same nonzero key, that nothing about the problem but the
     // values in the fronts has changed since the call that left its schedule on the device.
-    if (plan_key != 0 && dc->plan_key == plan_key && dc->plan_nf == nf && engine_mode ( ) == 0 && !g_profile_on
-        && lp.ntasks > 0)
-    {
-        hvec<double> none ;
-        return launch_rounds (dc, fronts, nf, none, none, stats, eng_verbose, eng_tlast) ;
-    }
+    if (plan_key != 0 && dc->plan_key == plan_key && dc->plan_nf == nf && engine_mode ( ) == 0 && lp.ntasks > 0)
+        return launch_rounds (dc, fronts, nf, stats, eng_verbose, eng_tlast) ;
     dc->plan_key = 0 ;          // the device buffers are about to be overwritten
 
     try
@@ -1099,8 +1134,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
         }
         for (int64_t b = 0 ; b < nbuckets ; b++) rptr [b+1] += rptr [b] ;
         const int64_t nrefs = rptr [nbuckets] ;
-        hvec<double> bflops, bbytes ;
-        if (g_profile_on)
+        hvec<double> bflops, bbytes ;       // per bucket, for the per-kernel profile
         {
             bflops.assign ((size_t) nbuckets, 0.0) ; bbytes.assign ((size_t) nbuckets, 0.0) ;
             for (int64_t i = 0 ; i < ntasks ; i++)
@@ -1330,7 +1364,8 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
             lp.rptr.swap (rptr) ; lp.bdep.swap (bdep) ; lp.done_last.swap (done_last) ;
             lp.nrounds = nrounds ; lp.nbuckets = nbuckets ; lp.ntasks = ntasks ; lp.nrefs = nrefs ; lp.flops = plan.flops ;
             dc->plan_key = plan_key ; dc->plan_nf = nf ;
-            return launch_rounds (dc, fronts, nf, bflops, bbytes, stats, eng_verbose, eng_tlast) ;
+            lp.bflops.swap (bflops) ; lp.bbytes.swap (bbytes) ;
+            return launch_rounds (dc, fronts, nf, stats, eng_verbose, eng_tlast) ;
         }
         if (stats)
         {

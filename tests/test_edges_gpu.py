@@ -123,3 +123,28 @@ def test_failing_host_allocator_reports_out_of_memory():
     # and the engine still works afterwards
     fronts, bufs = _device_fronts([A])
     assert ss.GPUQREngine(0, fronts, 1) == ss.QRENGINE_SUCCESS
+
+
+def test_repeated_device_batches_reuse_the_schedule_and_follow_the_values():
+    """The engine recognises a repeated problem description (same shapes, buffers, staircases) and
+    replays its schedule; the factors must follow the new values, and a different batch in between
+    must not be confused with it."""
+    import torch
+    rng = np.random.default_rng(8)
+    shapes = [(300, 77), (129, 129), (40, 203), (513, 31), (700, 260)]
+    mats = [rng.standard_normal(s) for s in shapes]
+    fronts, bufs = _device_fronts(mats)
+    other, _obufs = _device_fronts([rng.standard_normal((90, 40))])
+    for trial in range(3):
+        new = [rng.standard_normal(s) * (trial + 1) for s in shapes]
+        for t, A in zip(bufs, new):
+            t.copy_(torch.from_numpy(A))
+        assert ss.GPUQREngine(0, fronts, len(fronts)) == ss.QRENGINE_SUCCESS
+        torch.cuda.synchronize()
+        for A, t in zip(new, bufs):
+            m, n = A.shape
+            R = np.triu(t.cpu().numpy()[:min(m, n), :n])
+            Rref = np.triu(oracle.front_qr(A)[:min(m, n)])
+            assert r_rel_diff(R, Rref) <= 1e-12
+        if trial == 1:
+            assert ss.GPUQREngine(0, other, 1) == ss.QRENGINE_SUCCESS
