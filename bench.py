@@ -31,7 +31,7 @@ FN = [32, 64, 128, 256, 512, 1024, 2048]
 COPIES = 12
 PEAK_FP64_MFMA_TFLOPS = 78.6      # MI355X FP64 matrix peak = half the FP32-input MFMA rate (157.3 TF)
 PEAK_HBM_GBS = 8000.0
-KERNEL_NAMES = ["k_factorize<4>", "k_factorize<8>", "k_factorize<16>", "k_factorize<32>",
+KERNEL_NAMES = ["k_factorize<4, 8>", "k_factorize<4, 16>", "k_factorize<8, 16>", "k_factorize<16, 16>",
                 "k_apply<2>", "k_apply<4>", "k_apply<8>", "k_apply<16>", "k_assemble",
                 "k_factorize_all", "k_apply_small", "k_apply_all"]
 
