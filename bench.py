@@ -65,7 +65,7 @@ def cpu_baseline_sparse(kind, k):
     import time as _t
     from oracle import oracle
     from suitesparse_amd import problems, spqr
-    ks = min(k, 384 if kind == "sparse2d" else 28)
+    ks = min(k, 640 if kind == "sparse2d" else 36)      # about 10-20 s on one core
     shape = (ks, ks) if kind == "sparse2d" else (ks, ks, ks)
     A = problems.stacked_ls(shape)
     sym = spqr.analyze(A, problems.nested_dissection(shape, leaf=8), relax=20, gpuMemorySize=200 * 2**30)

@@ -1,0 +1,71 @@
+"""Summaries of rocprofv3's sqlite output (rocpd): per-kernel statistics of a --kernel-trace run as CSV,
+and per-kernel HBM traffic from two --pmc passes (FETCH_SIZE, WRITE_SIZE) as JSON + markdown table.
+
+  python scripts/rocpd_summary.py stats  kt_results.db  out.csv
+  python scripts/rocpd_summary.py pmc    f_results.db w_results.db  out.json out.md
+"""
+import csv
+import json
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    return name.split("(")[0]
+
+
+def stats(db_path, out_csv):
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
+                      "from kernels group by name order by sum(duration) desc").fetchall()
+    total = sum(r[2] for r in rows)
+    with open(out_csv, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for name, n, tot, avg, mn, mx in rows:
+            w.writerow([short(name)[:120], n, int(tot), "%.1f" % avg, "%.3f" % (100.0 * tot / total), mn, mx])
+
+
+def per_kernel(db_path, counter):
+    db = sqlite3.connect(db_path)
+    out = {}
+    for name, n, tot in db.execute("select name, count(*), sum(counter_value) from pmc_events "
+                                   "where counter_name = ? group by name", (counter,)):
+        k = short(name)
+        if k.startswith("k_"):
+            out[k] = (n, tot)
+    return out
+
+
+def pmc(fetch_db, write_db, out_json, out_md):
+    fe, wr = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(fe, key=lambda k: -fe[k][1]):
+        if k not in wr or wr[k][0] != fe[k][0]:
+            continue
+        n = fe[k][0]
+        fetch = 2.0 * 1024.0 * fe[k][1] / n         # KB -> bytes, doubled on gfx950
+        write = 1024.0 * wr[k][1] / n
+        kernels[k] = {"dispatches": n, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+                      "traffic_bytes_per_launch": fetch + write}
+    json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py "
+                          "--no-cpu-baseline --steps 1 --warmup 0",
+               "corrections": "counter unit KB; FETCH_SIZE doubled on gfx950 (128-B requests counted as 64 B); "
+                              "WRITE_SIZE as is",
+               "kernels": kernels}, open(out_json, "w"), indent=1)
+    with open(out_md, "w") as f:
+        f.write("| kernel | launches | FETCH_SIZE per launch | x2 | WRITE_SIZE per launch | traffic per launch |\n")
+        f.write("|---|---|---|---|---|---|\n")
+        for k, v in kernels.items():
+            f.write("| %s | %d | %.1f MB | %.1f MB | %.1f MB | **%.0f MB** |\n" % (
+                k, v["dispatches"], v["fetch_bytes_per_launch"] / 2e6, v["fetch_bytes_per_launch"] / 1e6,
+                v["write_bytes_per_launch"] / 1e6, v["traffic_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
