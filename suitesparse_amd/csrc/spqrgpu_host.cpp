@@ -327,12 +327,12 @@ struct Buf
     ~Buf ( ) { release ( ) ; }
 } ;
 
-struct Workspaces { Buf dF, dS, dR, dAx, dTasks, dPrefix, hBounce [2] ; } ;
+struct Workspaces { Buf dF, dS, dR, dR2, dAx, dTasks, dPrefix, hBounce [2] ; } ;
 
 // Device -> pageable host memory through two pinned bounce buffers: the DMA of one piece overlaps
 // the host threads copying the previous piece out (a direct copy into pageable memory ran at
 // 2.5 GB/s for the 87 GB of R of the 128^3 problem).
-static hipError_t copy_to_pageable (void *dst, const void *src_dev, size_t bytes, Buf bounce [2])
+static hipError_t copy_to_pageable (void *dst, const void *src_dev, size_t bytes, Buf bounce [2], hipStream_t stream = 0)
 {
     const size_t piece = (size_t) 256 << 20 ;
     hipError_t e ;
@@ -346,7 +346,7 @@ static hipError_t copy_to_pageable (void *dst, const void *src_dev, size_t bytes
         if (done < bytes)
         {
             len = std::min (piece, bytes - done) ;
-            if ((e = hipMemcpyAsync (bounce [cur].p, (const char *) src_dev + done, len, hipMemcpyDeviceToHost, 0)) != hipSuccess) return e ;
+            if ((e = hipMemcpyAsync (bounce [cur].p, (const char *) src_dev + done, len, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e ;
         }
         if (prev >= 0)
         {
@@ -362,7 +362,7 @@ static hipError_t copy_to_pageable (void *dst, const void *src_dev, size_t bytes
         }
         if (len > 0)
         {
-            if ((e = hipStreamSynchronize (0)) != hipSuccess) return e ;
+            if ((e = hipStreamSynchronize (stream)) != hipSuccess) return e ;
             prev = cur ; len_prev = len ; dst_prev = (char *) dst + done ;
             done += len ; cur ^= 1 ;
         }
@@ -380,9 +380,9 @@ extern "C" void spqrgpu_amd_finalize (void)
     for (int d = 0 ; d < MAX_WS_DEVICES ; d++)
     {
         Workspaces &W = g_ws [d] ;
-        if (!W.dF.p && !W.dS.p && !W.dR.p && !W.dAx.p && !W.dTasks.p && !W.dPrefix.p) continue ;
+        if (!W.dF.p && !W.dS.p && !W.dR.p && !W.dR2.p && !W.dAx.p && !W.dTasks.p && !W.dPrefix.p) continue ;
         if (hipSetDevice (d) != hipSuccess) continue ;
-        W.dF.release ( ) ; W.dS.release ( ) ; W.dR.release ( ) ; W.dAx.release ( ) ; W.dTasks.release ( ) ; W.dPrefix.release ( ) ;
+        W.dF.release ( ) ; W.dS.release ( ) ; W.dR.release ( ) ; W.dR2.release ( ) ; W.dAx.release ( ) ; W.dTasks.release ( ) ; W.dPrefix.release ( ) ;
         W.hBounce [0].release ( ) ; W.hBounce [1].release ( ) ;
     }
     if (cur >= 0) (void) hipSetDevice (cur) ;
@@ -429,7 +429,12 @@ static int factorize_impl
     int wdev = 0 ;
     if (hipGetDevice (&wdev) != hipSuccess || wdev < 0 || wdev >= MAX_WS_DEVICES) { free (num) ; return 2 ; }
     Workspaces &WS = g_ws [wdev] ;
-    Buf &dF = WS.dF, &dS = WS.dS, &dR = WS.dR, &dAx = WS.dAx, &dTasks = WS.dTasks, &dPrefix = WS.dPrefix ;
+    Buf &dF = WS.dF, &dS = WS.dS, &dAx = WS.dAx, &dTasks = WS.dTasks, &dPrefix = WS.dPrefix ;
+    // A pageable R stack is filled through bounce buffers; between stages that copy runs on a thread of
+    // its own beside the next stage, which then packs its R into the other of two device blocks.
+    std::thread r_thread ;
+    hipError_t r_thread_err = hipSuccess ;
+    auto join_r = [&] ( ) { if (r_thread.joinable ( )) r_thread.join ( ) ; return r_thread_err ; } ;
     std::vector<gpuqr_front> fronts ;
     std::vector<double *> limbo ;           // contribution blocks waiting on the host for a later stage
     std::vector<double *> limbo_dev ;       // ... or on the device, when it has the room (no PCIe round trip)
@@ -532,6 +537,7 @@ static int factorize_impl
             }
             if (dF.ensure ((size_t) std::max ((Long) 1, fsum) * sizeof (double)) != hipSuccess) { code = 1 ; goto done ; }
             if (dS.ensure ((size_t) std::max ((Long) 1, ssum) * sizeof (gpuqr_sentry)) != hipSuccess) { code = 1 ; goto done ; }
+            Buf &dR = (!num->RstackPinned && ngroups > 1 && (g & 1)) ? WS.dR2 : WS.dR ;
             if (dR.ensure ((size_t) std::max ((Long) 1, rsum) * sizeof (double)) != hipSuccess) { code = 1 ; goto done ; }
             double *F0 = (double *) dF.p ;
             gpuqr_sentry *S0 = (gpuqr_sentry *) dS.p ;
@@ -687,7 +693,19 @@ static int factorize_impl
                 else if (rsum > 0)
                 {
                     HIPCHK (hipStreamSynchronize (0)) ;
-                    HIPCHK (copy_to_pageable (num->Rstack + rhead, dR.p, (size_t) rsum * sizeof (double), WS.hBounce)) ;
+                    if (join_r ( ) != hipSuccess) { code = 2 ; goto done ; }       // one copy at a time: they share the bounce buffers
+                    double *dst = num->Rstack + rhead ;
+                    const void *src = dR.p ;
+                    const size_t bytes = (size_t) rsum * sizeof (double) ;
+                    if (g + 1 < ngroups && getenv ("GPUQR_SERIAL_R") == NULL)
+                    {
+                        r_thread = std::thread ([&WS, &r_thread_err, dst, src, bytes, wdev] ( )
+                        {
+                            r_thread_err = hipSetDevice (wdev) ;
+                            if (r_thread_err == hipSuccess) r_thread_err = copy_to_pageable (dst, src, bytes, WS.hBounce) ;
+                        }) ;
+                    }
+                    else HIPCHK (copy_to_pageable (dst, src, bytes, WS.hBounce)) ;
                 }
                 rhead += rsum ;
             }
@@ -759,6 +777,7 @@ static int factorize_impl
     }
 
 done:
+    if (join_r ( ) != hipSuccess && code == 0) code = 2 ;
     for (size_t i = 0 ; i < limbo.size ( ) ; i++) free (limbo [i]) ;
     for (size_t i = 0 ; i < limbo_dev.size ( ) ; i++) if (limbo_dev [i]) (void) hipFree (limbo_dev [i]) ;
     for (size_t i = 0 ; i < used_dev.size ( ) ; i++) (void) hipFree (used_dev [i]) ;

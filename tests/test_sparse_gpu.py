@@ -153,6 +153,24 @@ def test_pageable_r_stack_fallback(monkeypatch):
     assert (r0.R != r1.R).nnz == 0
 
 
+def test_pageable_r_stack_with_stages_copies_beside_the_next_stage(monkeypatch):
+    """Several stages and a pageable stack: the R of a stage is copied out by a helper thread while
+    the next stage runs (two device blocks take turns); same R as the pinned, one-stage run."""
+    grid = (40, 40)
+    A = problems.stacked_ls(grid)
+    Q = problems.nested_dissection(grid, leaf=4)
+    one = spqr.factorize(spqr.analyze(A, Q, relax=0, gpuMemorySize=2**34), A)
+    sym = spqr.analyze(A, Q, relax=0, gpuMemorySize=10_700_000)
+    assert sym.numStages > 2
+    monkeypatch.setenv("GPUQR_PAGEABLE_R", "1")
+    r1 = spqr.factorize(sym, A)
+    monkeypatch.setenv("GPUQR_SERIAL_R", "1")
+    r2 = spqr.factorize(sym, A)
+    assert r1.numStagesRun == sym.numStages
+    assert (r1.R != r2.R).nnz == 0
+    assert (r1.R != one.R).nnz == 0 or np.abs((r1.R - one.R)).max() <= 1e-13 * np.abs(one.R).max()
+
+
 @pytest.mark.parametrize("grid,leaf,mem,mode", [((30, 30), 4, 2**34, 0), ((10, 10, 10), 2, 2**34, 0),
                                                 ((30, 30), 4, 2**22, 0), ((30, 30), 4, 2**34, 1)])
 def test_r_packed_inside_the_engine_equals_r_packed_afterwards(monkeypatch, grid, leaf, mem, mode):
