@@ -265,6 +265,7 @@ def main():
                                    else cpu_baseline_sparse(*[f(x) for f, x in zip((str, int), args.workload.split(":"))]))
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()                  # rank 0 is still profiling and printing while the others arrive here
         dist.destroy_process_group()
 
 
