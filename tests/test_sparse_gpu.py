@@ -211,3 +211,65 @@ def test_repeated_factorizations_reuse_the_schedule_and_follow_the_values(monkey
     r2n = spqr.factorize(sym, A2)
     assert (r1.R != r1n.R).nnz == 0 and (r3.R != r1n.R).nnz == 0
     assert (r2.R != r2n.R).nnz == 0 and (r2.R != r1.R).nnz > 0
+
+
+def _config1_matrix():
+    """Stand-in for ash219 (219 x 85, 0/1 entries, two per row), which is not in the reference tree:
+    same shape and density from a seeded generator."""
+    rng = np.random.default_rng(219)
+    rows = np.repeat(np.arange(219), 2)
+    cols = np.concatenate([rng.choice(85, size=2, replace=False) for _ in range(219)])
+    return sp.csc_matrix((np.ones(438), (rows, cols)), shape=(219, 85))
+
+
+def test_config1_small_rectangular_least_squares():
+    """The plumbing case of the reference's qrdemo (SPQR/Demo/qrdemo.cpp: min ||Ax - b||, b = ones)
+    on the ash219 stand-in: R against LAPACK and the oracle, and the residual checks the demo prints."""
+    A = _config1_matrix()
+    m, n = A.shape
+    assert np.linalg.matrix_rank(A.toarray()) == n
+    sym = spqr.analyze(A, None, relax=0, gpuMemorySize=2**30)
+    res = spqr.factorize(sym, A)
+    assert res.rank == n
+    R = _dense_R(res, n)
+    Rl = np.linalg.qr(A[:, sym.Qfill].toarray(), mode="r")
+    assert r_rel_diff(rownorm_sign(R), rownorm_sign(Rl)) <= 1e-12
+    Farena, FOff = oracle.multifrontal(sym, spqr.s_values(sym, A))
+    assert r_rel_diff(rownorm_sign(R), rownorm_sign(oracle.r_from_fronts(sym, Farena, FOff))) <= 1e-12
+    b = np.ones((m, 1))
+    x, _, _ = spqr.qr_solve(A, b, None, relax=0)
+    xref = np.linalg.lstsq(A.toarray(), b, rcond=None)[0]
+    assert np.abs(x - xref).max() <= 1e-10 * max(1.0, np.abs(xref).max())
+    r = A @ x - b
+    assert np.abs(A.T @ r).max() <= 1e-10 * np.abs(A).sum()          # ||A'(Ax-b)||, qrdemo's second check
+
+
+def test_config5_dependent_columns_show_on_the_diagonal():
+    """Duplicated and nearly dependent columns.  The device path has no rank detection (the reference
+    turns its GPU off when a tolerance is asked for, SPQR/Source/spqr_analyze.cpp:120-125), so the
+    factorization runs structurally: R'R = A'A still holds to rounding, and the dependent columns are
+    exactly those whose diagonal entry falls under SPQR's default tolerance
+    20 (m+n) eps max||A(:,j)|| (SPQR/Source/spqr_tol.cpp:23-24)."""
+    grid = (24, 24)
+    A0 = problems.stacked_ls(grid)
+    n0 = A0.shape[1]
+    rng = np.random.default_rng(5)
+    dup = rng.choice(n0, size=12, replace=False)
+    near = rng.choice(n0, size=12, replace=False)
+    Anear = A0[:, near].toarray()
+    Anear = Anear + 1e-14 * rng.standard_normal(Anear.shape) * (Anear != 0)
+    A = sp.csc_matrix(sp.hstack([A0, A0[:, dup], sp.csc_matrix(Anear)]))
+    m, n = A.shape
+    Q = np.concatenate([problems.nested_dissection(grid, leaf=4), np.arange(n0, n)])
+    sym = spqr.analyze(A, Q, relax=0, gpuMemorySize=2**32)
+    res = spqr.factorize(sym, A)
+    R = _dense_R(res, n)
+    AQ = A[:, sym.Qfill].toarray()
+    G = AQ.T @ AQ
+    assert np.linalg.norm(R.T @ R - G, 1) / np.linalg.norm(G, 1) <= 1e-12
+    tol = 20.0 * (m + n) * np.finfo(float).eps * np.sqrt((AQ * AQ).sum(axis=0)).max()
+    dead = np.abs(np.diag(R)) <= tol
+    assert dead.sum() == 24
+    assert np.linalg.matrix_rank(AQ, tol=tol) == n - 24
+    # the dead ones are the appended copies (they come last in the column order)
+    assert set(np.nonzero(dead)[0]) == set(np.nonzero(sym.Qfill >= n0)[0])
