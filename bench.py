@@ -248,6 +248,15 @@ def main():
                         "unit": "TFLOP/s", "frac": tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
                         "avg_launch_us": avg_s * 1e6, "launches": ln}
 
+    # the assembly kernels (S entries and contribution blocks) against the same HBM peak
+    roofline_assembly = None
+    if rank == 0 and "k_assemble" in per_kernel and per_kernel["k_assemble"]["ms"] > 0:
+        ka = per_kernel["k_assemble"]
+        gbs_a = ka["gbytes"] / (ka["ms"] / 1e3)
+        roofline_assembly = {"kernel": "k_assemble", "bound": "hbm", "achieved": gbs_a, "peak": PEAK_HBM_GBS,
+                             "unit": "GB/s", "frac": gbs_a / PEAK_HBM_GBS, "traffic": None,
+                             "avg_launch_us": ka["ms"] * 1e3 / ka["launches"], "launches": ka["launches"]}
+
     if rank == 0:
         strong = args.workload != "dense"          # the sparse problems are one fixed job split over the ranks
         value = (1 if strong else world) * flops * K / elapsed / 1e9
@@ -260,6 +269,8 @@ def main():
             "pct_fp64_mfma_peak": 100.0 * value / world / 1e3 / PEAK_FP64_MFMA_TFLOPS,
             "roofline": roofline, "per_kernel": per_kernel,
         }
+        if roofline_assembly is not None:
+            out["roofline_assembly"] = roofline_assembly
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = (cpu_baseline_dense() if args.workload == "dense"
                                    else cpu_baseline_sparse(*[f(x) for f, x in zip((str, int), args.workload.split(":"))]))
