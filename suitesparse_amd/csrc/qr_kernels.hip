@@ -685,16 +685,40 @@ __device__ void packassemble (const QrPackAssembleTask &t, char *smem)
     __syncthreads ( ) ;
     // one wave per row of the tile, lanes along the (contiguous) child columns;
     // only the upper trapezoid cj >= ci carries data (packAssemble.cu:47-55)
+    // (four rows and both halves of the tile's columns are fetched before anything is stored: eight
+    // loads in flight per lane instead of one)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6 ;
-    for (int cil = wave ; cil < ctm ; cil += 4)
+    static_assert (QR_PACK_TILE == 128, "two 64-lane passes cover the columns of a tile") ;
+    for (int cil0 = wave ; cil0 < ctm ; cil0 += 16)
     {
-        const int ci = t.cistart + cil ;
-        gcdouble *Crow = (gcdouble *) t.C + (size_t) ci * t.cld ;
-        gdouble *Prow = (gdouble *) t.P + (size_t) shRimap [cil] * t.pn ;
-        for (int cjl = lane ; cjl < ctn ; cjl += 64)
+        double v [4][2] ;
+        #pragma unroll
+        for (int u = 0 ; u < 4 ; u++)
         {
-            int cj = t.cjstart + cjl ;
-            if (cj >= ci) Prow [shRjmap [cjl]] = Crow [cj] ;
+            // unconditional loads through clamped indices (every entry of the tile's rows is memory
+            // of the child's block, also below its diagonal): no branch, no wait behind a load
+            const int cil = (cil0 + 4*u < ctm) ? (cil0 + 4*u) : (ctm - 1) ;
+            gcdouble *Crow = (gcdouble *) t.C + (size_t) (t.cistart + cil) * t.cld + t.cjstart ;
+            #pragma unroll
+            for (int h = 0 ; h < 2 ; h++)
+            {
+                const int cjl = (lane + 64*h < ctn) ? (lane + 64*h) : (ctn - 1) ;
+                v [u][h] = Crow [cjl] ;
+            }
+        }
+        #pragma unroll
+        for (int u = 0 ; u < 4 ; u++)
+        {
+            const int cil = cil0 + 4*u ;
+            if (cil >= ctm) break ;
+            const int ci = t.cistart + cil ;
+            gdouble *Prow = (gdouble *) t.P + (size_t) shRimap [cil] * t.pn ;
+            #pragma unroll
+            for (int h = 0 ; h < 2 ; h++)
+            {
+                const int cjl = lane + 64*h ;
+                if (cjl < ctn && t.cjstart + cjl >= ci) Prow [shRjmap [cjl]] = v [u][h] ;
+            }
         }
     }
 }
