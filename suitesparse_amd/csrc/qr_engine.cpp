@@ -954,7 +954,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
     // the upload of the tasks just the same.
     static int auto_key = -1 ;
     if (auto_key < 0) auto_key = (getenv ("GPUQR_NO_PLAN_CACHE") == NULL) ? 1 : 0 ;
-    if (plan_key == 0 && auto_key && engine_mode ( ) == 0)
+    if (plan_key == 0 && auto_key && engine_mode ( ) != 1)
     {
         plan_key = problem_fingerprint (fronts, nf) ;
         ENG_TICK ("fingerprint") ;
@@ -962,7 +962,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
 
     // The caller vouches, by passing the same nonzero key, that nothing about the problem but the
     // values in the fronts has changed since the call that left its schedule on the device.
-    if (plan_key != 0 && dc->plan_key == plan_key && dc->plan_nf == nf && engine_mode ( ) == 0 && lp.ntasks > 0)
+    if (plan_key != 0 && dc->plan_key == plan_key && dc->plan_nf == nf && engine_mode ( ) != 1 && lp.ntasks > 0)
         return launch_rounds (dc, fronts, nf, stats, eng_verbose, eng_tlast) ;
     dc->plan_key = 0 ;          // the device buffers are about to be overwritten
 
