@@ -21,6 +21,9 @@ def _cases():
         [sp.identity(120), sp.csc_matrix((180, 120))])
     yield "random", sp.csc_matrix(R), rng.permutation(120)
     yield "natural-order", problems.stacked_ls((10, 10)), None
+    # sizes at which fronts have several panels, several 256-row chunks and merge levels
+    yield "3d-14", problems.stacked_ls((14, 14, 14)), problems.nested_dissection((14, 14, 14), leaf=3)
+    yield "2d-72", problems.stacked_ls((72, 72)), problems.nested_dissection((72, 72), leaf=6)
 
 
 CASES = list(_cases())
