@@ -3,6 +3,7 @@ and per-kernel HBM traffic from two --pmc passes (FETCH_SIZE, WRITE_SIZE) as JSO
 
   python scripts/rocpd_summary.py stats  kt_results.db  out.csv
   python scripts/rocpd_summary.py pmc    f_results.db w_results.db  out.json out.md
+  python scripts/rocpd_summary.py gaps   kt_results.db
 """
 import csv
 import json
@@ -64,8 +65,46 @@ def pmc(fetch_db, write_db, out_json, out_md):
                 v["write_bytes_per_launch"] / 1e6, v["traffic_bytes_per_launch"] / 1e6))
 
 
+def gaps(db_path):
+    """Per hardware queue of the longest engine call in a --kernel-trace run: kernels, busy time, idle
+    time between kernels, and how long after the latest kernel end anywhere on the device each kernel
+    started (the start latency of a launch that waited for another queue's kernel)."""
+    import bisect
+    import collections
+    import statistics
+    db = sqlite3.connect(db_path)
+    rows = [(short(n), s, e, q) for n, s, e, q in
+            db.execute("select name, start, end, queue_id from kernels order by start") if short(n).startswith("k_")]
+    calls = [[rows[0]]]
+    for r in rows[1:]:
+        if r[1] - calls[-1][-1][2] > 3e6:           # engine calls are separated by milliseconds of host work
+            calls.append([])
+        calls[-1].append(r)
+    big = sorted(calls, key=len)[-2] if len(calls) > 1 else calls[0]      # the last but one: the timed step
+    print("kernels %d, span %.1f ms" % (len(big), (max(x[2] for x in big) - big[0][1]) / 1e6))
+    ends = sorted(x[2] for x in big)
+    byq = collections.defaultdict(list)
+    for x in big:
+        byq[x[3]].append(x)
+    for q, l in sorted(byq.items()):
+        l.sort(key=lambda x: x[1])
+        busy = sum(x[2] - x[1] for x in l)
+        idle = sum(max(0, l[i + 1][1] - l[i][2]) for i in range(len(l) - 1))
+        lat = []
+        for x in l:
+            i = bisect.bisect_right(ends, x[1]) - 1
+            if i >= 0:
+                lat.append(x[1] - ends[i])
+        names = collections.Counter(x[0] for x in l).most_common(2)
+        print("queue %d: %5d kernels, busy %.1f ms, idle between kernels %.1f ms, start latency median %.1f us, "
+              "sum %.1f ms  %s" % (q, len(l), busy / 1e6, idle / 1e6, statistics.median(lat) / 1e3 if lat else 0.0,
+                                   sum(lat) / 1e6, names))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "gaps":
+        gaps(sys.argv[2])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
