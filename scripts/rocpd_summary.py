@@ -80,7 +80,8 @@ def gaps(db_path):
         if r[1] - calls[-1][-1][2] > 3e6:           # engine calls are separated by milliseconds of host work
             calls.append([])
         calls[-1].append(r)
-    big = sorted(calls, key=len)[-2] if len(calls) > 1 else calls[0]      # the last but one: the timed step
+    whole = [c for c in calls if len(c) >= 0.9 * max(len(x) for x in calls)]    # warm-up, timed and profiled steps
+    big = whole[1] if len(whole) > 1 else whole[0]                              # the timed one
     print("kernels %d, span %.1f ms" % (len(big), (max(x[2] for x in big) - big[0][1]) / 1e6))
     ends = sorted(x[2] for x in big)
     byq = collections.defaultdict(list)
