@@ -39,6 +39,8 @@ extern "C" hipError_t qr_launch_pack_r (const QrPackRTask *d_tasks, const long l
 extern "C" hipError_t qr_launch_tasks (int kid, const QrTask *d_tasks, const QrRef *d_refs, int nrefs, hipStream_t stream) ;
 extern "C" hipError_t qr_launch_tasks_ev (int kid, const QrTask *d_tasks, const QrRef *d_refs, int nrefs, hipStream_t stream,
     hipEvent_t stop) ;
+extern "C" hipError_t qr_launch_tasks_timed (int kid, const QrTask *d_tasks, const QrRef *d_refs, int nrefs, hipStream_t stream,
+    hipEvent_t start, hipEvent_t stop) ;
 extern "C" hipError_t qr_kernels_init (void) ;
 extern "C" hipError_t qr_launch_persistent (const QrTask *d_tasks, const QrQueueRef *d_refs, int nrefs,
     int *d_counters, int nworkgroups, hipStream_t stream) ;
@@ -818,9 +820,7 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
                         HIP_TRY (hipEventCreate (&e0)) ; evProf.push_back (e0) ;
                         HIP_TRY (hipEventCreate (&e1)) ; evProf.push_back (e1) ;
                         evProfBucket.push_back (b) ; evProfN.push_back (n) ; evProfKid.push_back (kid) ;
-                        HIP_TRY (hipEventRecord (e0, st)) ;
-                        HIP_TRY (qr_launch_tasks (kid, d_tasks, d_refs + rptr [b], (int) n, st)) ;
-                        HIP_TRY (hipEventRecord (e1, st)) ;
+                        HIP_TRY (qr_launch_tasks_timed (kid, d_tasks, d_refs + rptr [b], (int) n, st, e0, e1)) ;
                     }
                     else if (i == last_of [x])
                     {

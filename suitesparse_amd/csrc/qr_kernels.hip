@@ -1086,35 +1086,42 @@ extern "C" hipError_t qr_launch_persistent (const QrTask *d_tasks, const QrQueue
 }
 
 // Launch nrefs workgroups of kernel id kid: workgroup b runs (task, block) = d_refs [b].
-// stop != NULL: the event becomes the completion signal of the launch (no separate marker packet)
-extern "C" hipError_t qr_launch_tasks_ev (int kid, const QrTask *d_tasks, const QrRef *d_refs, int nrefs, hipStream_t stream,
-    hipEvent_t stop)
+// start / stop != NULL: the events are taken by the launch itself (the stop event is its completion
+// signal; no separate marker packets)
+extern "C" hipError_t qr_launch_tasks_timed (int kid, const QrTask *d_tasks, const QrRef *d_refs, int nrefs, hipStream_t stream,
+    hipEvent_t start, hipEvent_t stop)
 {
     if (nrefs <= 0) return hipSuccess ;
     const dim3 grid (nrefs), block (QR_THREADS), fblock (QR_FACT_THREADS) ;
     const size_t lds = kernel_lds_bytes (kid) ;
     switch (kid)
     {
-        case 0: hipExtLaunchKernelGGL ((k_factorize<4, 8>),   grid, block,  lds, stream, NULL, stop, 0, d_tasks, d_refs) ; break ;
-        case 1: hipExtLaunchKernelGGL ((k_factorize<4, 16>),  grid, fblock, lds, stream, NULL, stop, 0, d_tasks, d_refs) ; break ;
-        case 2: hipExtLaunchKernelGGL ((k_factorize<8, 16>),  grid, fblock, lds, stream, NULL, stop, 0, d_tasks, d_refs) ; break ;
-        case 3: hipExtLaunchKernelGGL ((k_factorize<16, 16>), grid, fblock, lds, stream, NULL, stop, 0, d_tasks, d_refs) ; break ;
-        case 4: hipExtLaunchKernelGGL (k_apply<2>,      grid, block, lds, stream, NULL, stop, 0, d_tasks, d_refs) ; break ;
-        case 5: hipExtLaunchKernelGGL (k_apply<4>,      grid, block, lds, stream, NULL, stop, 0, d_tasks, d_refs) ; break ;
-        case 6: hipExtLaunchKernelGGL (k_apply<8>,      grid, block, lds, stream, NULL, stop, 0, d_tasks, d_refs) ; break ;
-        case 7: hipExtLaunchKernelGGL (k_apply<16>,     grid, block, lds, stream, NULL, stop, 0, d_tasks, d_refs) ; break ;
-        case 8: hipExtLaunchKernelGGL (k_assemble,      grid, block, lds, stream, NULL, stop, 0, d_tasks, d_refs) ; break ;
-        case 9:  hipExtLaunchKernelGGL (k_factorize_all, grid, fblock, lds, stream, NULL, stop, 0, d_tasks, d_refs) ; break ;  // tiers 0..3
-        case 10: hipExtLaunchKernelGGL (k_apply_small,   grid, block, lds, stream, NULL, stop, 0, d_tasks, d_refs) ; break ;   // tiers 0..2
-        case 11: hipExtLaunchKernelGGL (k_apply_all,     grid, block, lds, stream, NULL, stop, 0, d_tasks, d_refs) ; break ;   // tiers 0..3
+        case 0: hipExtLaunchKernelGGL ((k_factorize<4, 8>),   grid, block,  lds, stream, start, stop, 0, d_tasks, d_refs) ; break ;
+        case 1: hipExtLaunchKernelGGL ((k_factorize<4, 16>),  grid, fblock, lds, stream, start, stop, 0, d_tasks, d_refs) ; break ;
+        case 2: hipExtLaunchKernelGGL ((k_factorize<8, 16>),  grid, fblock, lds, stream, start, stop, 0, d_tasks, d_refs) ; break ;
+        case 3: hipExtLaunchKernelGGL ((k_factorize<16, 16>), grid, fblock, lds, stream, start, stop, 0, d_tasks, d_refs) ; break ;
+        case 4: hipExtLaunchKernelGGL (k_apply<2>,      grid, block, lds, stream, start, stop, 0, d_tasks, d_refs) ; break ;
+        case 5: hipExtLaunchKernelGGL (k_apply<4>,      grid, block, lds, stream, start, stop, 0, d_tasks, d_refs) ; break ;
+        case 6: hipExtLaunchKernelGGL (k_apply<8>,      grid, block, lds, stream, start, stop, 0, d_tasks, d_refs) ; break ;
+        case 7: hipExtLaunchKernelGGL (k_apply<16>,     grid, block, lds, stream, start, stop, 0, d_tasks, d_refs) ; break ;
+        case 8: hipExtLaunchKernelGGL (k_assemble,      grid, block, lds, stream, start, stop, 0, d_tasks, d_refs) ; break ;
+        case 9:  hipExtLaunchKernelGGL (k_factorize_all, grid, fblock, lds, stream, start, stop, 0, d_tasks, d_refs) ; break ;  // tiers 0..3
+        case 10: hipExtLaunchKernelGGL (k_apply_small,   grid, block, lds, stream, start, stop, 0, d_tasks, d_refs) ; break ;   // tiers 0..2
+        case 11: hipExtLaunchKernelGGL (k_apply_all,     grid, block, lds, stream, start, stop, 0, d_tasks, d_refs) ; break ;   // tiers 0..3
         default: return hipErrorInvalidValue ;
     }
     return hipGetLastError ( ) ;
 }
 
+extern "C" hipError_t qr_launch_tasks_ev (int kid, const QrTask *d_tasks, const QrRef *d_refs, int nrefs, hipStream_t stream,
+    hipEvent_t stop)
+{
+    return qr_launch_tasks_timed (kid, d_tasks, d_refs, nrefs, stream, NULL, stop) ;
+}
+
 extern "C" hipError_t qr_launch_tasks (int kid, const QrTask *d_tasks, const QrRef *d_refs, int nrefs, hipStream_t stream)
 {
-    return qr_launch_tasks_ev (kid, d_tasks, d_refs, nrefs, stream, NULL) ;
+    return qr_launch_tasks_timed (kid, d_tasks, d_refs, nrefs, stream, NULL, NULL) ;
 }
 
 extern "C" hipError_t qr_kernels_init (void)
