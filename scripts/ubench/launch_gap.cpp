@@ -8,6 +8,14 @@
 #include <vector>
 #include <chrono>
 __global__ void k_tiny (int *p) { if (threadIdx.x == 0) p [blockIdx.x] += 1 ; }
+// holds the queue for about `cycles` shader clocks, so that what the host enqueues meanwhile is timed
+// on the device alone
+__global__ void k_hold (long long cycles, int *p)
+{
+    const long long t0 = __builtin_amdgcn_s_memtime ( ) ;
+    while (__builtin_amdgcn_s_memtime ( ) - t0 < cycles) __builtin_amdgcn_s_sleep (16) ;
+    if (p == NULL) return ;
+}
 static double now_ms ( ) { return std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now ( ).time_since_epoch ( )).count ( ) ; }
 int main ( )
 {
@@ -22,6 +30,12 @@ int main ( )
         for (int rep = 0 ; rep < 2 ; rep++)
         {
             (void) hipDeviceSynchronize ( ) ;
+            // device-side time: a hold kernel on stream 0 (100 M clocks at 100 MHz would be far too long: the
+            // counter runs at about 100 MHz here, 4 M ticks = 40 ms), then the chain behind it, timed by events
+            hipEvent_t d0, d1 ;
+            (void) hipEventCreate (&d0) ; (void) hipEventCreate (&d1) ;
+            hipLaunchKernelGGL (k_hold, dim3 (1), dim3 (64), 0, s [0], 4000000LL, (int *) NULL) ;
+            (void) hipEventRecord (d0, s [0]) ;
             double t0 = now_ms ( ) ;
             for (int i = 0 ; i < n ; i++)
             {
@@ -33,9 +47,15 @@ int main ( )
                 if (variant == 1 || variant == 2) (void) hipEventRecord (ev [i], st) ;
             }
             double t1 = now_ms ( ) ;
+            const bool two_streams = (variant == 2 || variant == 4) ;
+            hipStream_t last = two_streams ? s [(n - 1) & 1] : s [0] ;
+            (void) hipEventRecord (d1, last) ;
             (void) hipDeviceSynchronize ( ) ;
-            double t2 = now_ms ( ) ;
-            if (rep == 1) printf ("variant %d: host %.2f us per launch, total %.2f us per launch\n", variant, (t1 - t0) * 1e3 / n, (t2 - t0) * 1e3 / n) ;
+            float dev_ms = 0 ;
+            (void) hipEventElapsedTime (&dev_ms, d0, d1) ;
+            if (rep == 1) printf ("variant %d: host %.2f us per launch, device %.2f us per launch (chain queued behind a hold kernel)\n",
+                variant, (t1 - t0) * 1e3 / n, dev_ms * 1e3 / n) ;
+            (void) hipEventDestroy (d0) ; (void) hipEventDestroy (d1) ;
         }
     }
     int h [4] ;

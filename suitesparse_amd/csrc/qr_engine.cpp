@@ -758,12 +758,12 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
                     int64_t n = rptr [b+1] - rptr [b] ;
                     int kid = slot_kernel (slot) ;
                     int32_t dmerged [QR_NCLASS] = {bdep [b*QR_NCLASS], bdep [b*QR_NCLASS + 1], bdep [b*QR_NCLASS + 2]} ;
-                    if (merge_tiers && (slot == 0 || slot == 4))
+                    if (merge_tiers && (slot == 0 || slot == 4 || slot == 9))
                     {
-                        const int last = (slot == 0) ? 3 : 6 ;
+                        const int last = (slot == 0) ? 3 : ((slot == 4) ? 6 : 12) ;
                         const int64_t bl = (int64_t) r * QR_NSLOTS + last ;
                         n = rptr [bl+1] - rptr [b] ;
-                        kid = (slot == 0) ? 9 : 10 ;
+                        kid = (slot == 0) ? 9 : ((slot == 4) ? 10 : 11) ;      // 11: every update tier (the look-ahead updates)
                         // a single tier keeps its own kernel (fewer registers, more workgroups per CU)
                         int present = 0, only = slot ;
                         for (int64_t bb = b ; bb <= bl ; bb++) if (rptr [bb+1] > rptr [bb]) { present++ ; only = (int) (bb % QR_NSLOTS) ; }
@@ -771,7 +771,7 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
                         for (int64_t bb = b + 1 ; bb <= bl ; bb++)
                             for (int c = 0 ; c < QR_NCLASS ; c++) dmerged [c] = std::max (dmerged [c], bdep [bb*QR_NCLASS + c]) ;
                     }
-                    else if (merge_tiers && ((slot >= 1 && slot <= 3) || slot == 5 || slot == 6)) continue ;
+                    else if (merge_tiers && ((slot >= 1 && slot <= 3) || slot == 5 || slot == 6 || slot >= 10)) continue ;
                     // a 256-row update launch too small to fill the chip takes the small tiers of its round
                     // along (slots 4..7 are neighbours in the workgroup list)
                     const int64_t b4 = (int64_t) r * QR_NSLOTS + 4, b7 = (int64_t) r * QR_NSLOTS + 7 ;
