@@ -47,13 +47,6 @@ int main (int argc, char **argv)
         float ms ; hipEventElapsedTime (&ms, e0, e1) ;
         if (r > 0 && ms < best) best = ms ;
     }
-#ifdef FACT_STATS
-    unsigned long long st [8] ;
-    hipMemcpyFromSymbol (st, HIP_SYMBOL (g_fact_stats), sizeof (st)) ;
-    double n = (double) ntask * (reps + 1) ;
-    printf ("cycles per task (100 MHz ticks x ?): load %.0f  steps0-7 %.0f  steps8-31 %.0f  writeback %.0f  build_t %.0f\n",
-        st [0] / n, st [1] / n, st [2] / n, st [3] / n, st [4] / n) ;
-#endif
     printf ("factorize tasks %d K %d ld %d: %.1f us per launch, %.2f us per task per CU slot\n", ntask, K, ld,
         best * 1e3, best * 1e3 / ((ntask + 255) / 256)) ;
     return 0 ;

@@ -460,7 +460,7 @@ struct DeviceCache
     LaunchPlan lp ;
     uint64_t plan_key = 0 ;         // key of the schedule whose tasks sit in d_tasks / d_refs (0: none)
     int64_t plan_nf = 0 ;
-    hipStream_t sCompute = NULL, sApply = NULL, sSmall = NULL, sCopy = NULL ;
+    hipStream_t sCompute = NULL, sApply = NULL, sCopy = NULL ;
     hipEvent_t evStart = NULL, evStop = NULL ;
     std::vector<hipEvent_t> evPool ;        // untimed events, reused by every call
     void *d_tasks = NULL, *d_refs = NULL, *d_vt = NULL, *h_stage = NULL, *d_counters = NULL, *d_pack = NULL ;
@@ -493,7 +493,6 @@ struct DeviceCache
     {
         if (sCompute) (void) hipStreamDestroy (sCompute) ;
         if (sApply) (void) hipStreamDestroy (sApply) ;
-        if (sSmall) (void) hipStreamDestroy (sSmall) ;
         if (sCopy) (void) hipStreamDestroy (sCopy) ;
         for (size_t i = 0 ; i < evPool.size ( ) ; i++) (void) hipEventDestroy (evPool [i]) ;
         if (evStart) (void) hipEventDestroy (evStart) ;
@@ -524,8 +523,6 @@ static DeviceCache *device_cache (void)
         if (hipDeviceGetStreamPriorityRange (&prio_lo, &prio_hi) != hipSuccess) { prio_lo = prio_hi = 0 ; }
         if (hipStreamCreateWithPriority (&dc->sCompute, hipStreamNonBlocking, prio_hi) != hipSuccess) { dc->release ( ) ; return NULL ; }
         if (hipStreamCreateWithPriority (&dc->sApply, hipStreamNonBlocking, prio_lo) != hipSuccess) { dc->release ( ) ; return NULL ; }
-        { const char *e = getenv ("GPUQR_STREAMS") ;
-          if (e && atoi (e) == 3 && hipStreamCreateWithPriority (&dc->sSmall, hipStreamNonBlocking, prio_lo) != hipSuccess) { dc->release ( ) ; return NULL ; } }
         if (hipStreamCreateWithFlags (&dc->sCopy, hipStreamNonBlocking) != hipSuccess) { dc->release ( ) ; return NULL ; }
         if (hipEventCreate (&dc->evStart) != hipSuccess) { dc->release ( ) ; return NULL ; }
         if (hipEventCreate (&dc->evStop) != hipSuccess) { dc->release ( ) ; return NULL ; }
@@ -700,14 +697,12 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
                     return (ra != rb) ? (ra < rb) : (a < b) ;
                 }) ;
 
-            // Three compute streams, one per class.  The launches of a class are queued in round
+            // Two compute streams for three classes.  The launches of a class are queued in round
             // order; before a launch its stream waits for the event of the latest round of each
-            // other class that the tasks of the launch depend on, and for nothing else.
-            // (classes 0 and 2 share a stream unless GPUQR_STREAMS=3: every stream costs the process a
-            // hardware queue, and with several processes on one device a fifth queue per process was
-            // seen to stall the whole device)
-            static int nstreams = 0 ;
-            if (nstreams == 0) { const char *e = getenv ("GPUQR_STREAMS") ; nstreams = (e && atoi (e) == 3) ? 3 : 2 ; }
+            // class on the other stream that the tasks of the launch depend on, and for nothing else.
+            // With the copy stream and the null stream that the SPQR driver uses, a process holds four
+            // streams: one per hardware queue HIP gives a process by default, so no two of them are
+            // multiplexed onto one queue.
             // Class 2 joins the lighter of the two streams.  Rough launch times (us per 512 workgroups,
             // measured): factorize 40/40/50/62 by tier, updates 12/17/28/80 by tier.
             int small_on ;
@@ -723,7 +718,7 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
                 const char *e = getenv ("GPUQR_SMALL_ON") ;
                 if (e) small_on = atoi (e) ;
             }
-            hipStream_t cstream [QR_NCLASS] = {sCompute, sApply, (nstreams == 3) ? dc->sSmall : (small_on ? sApply : sCompute)} ;
+            hipStream_t cstream [QR_NCLASS] = {sCompute, sApply, small_on ? sApply : sCompute} ;
             HIP_TRY (hipEventRecord (evStart, sCompute)) ;
             for (int c = 1 ; c < QR_NCLASS ; c++) HIP_TRY (hipStreamWaitEvent (cstream [c], evStart, 0)) ;    // the task upload
             size_t pi = 0, nev = 0 ;
@@ -854,10 +849,22 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
                     }
                     else evAt [c][r] = (r > 0) ? evAt [c][r-1] : (hipEvent_t) NULL ;
                 }
-                if (rode)
+                if (rode && cstream [2] != cstream [1] && launched [2])
                 {
-                    // class-2 tasks of this round ran on the bulk stream: whoever waits for class 2 of this
-                    // round waits for that launch, and the class-2 stream stays in order behind it
+                    // Class-2 update tasks of this round ran on the bulk stream, and the round's assembly
+                    // launch ran on the class-2 stream.  The class-2 stream is told to wait for the bulk
+                    // launch and a fresh event is recorded behind that wait, so whoever waits for class 2
+                    // of this round waits for both.
+                    HIP_TRY (hipStreamWaitEvent (cstream [2], evAt [1][r], 0)) ;
+                    hipEvent_t ev = dc->pooled_event (nev++) ;
+                    if (!ev) { code = GPUQR_GPUERROR ; goto cleanup ; }
+                    HIP_TRY (hipEventRecord (ev, cstream [2])) ;
+                    evAt [2][r] = ev ;
+                    for (int c2 = 0 ; c2 < 2 ; c2++) if (cstream [c2] == cstream [2]) evAt [c2][r] = ev ;
+                }
+                else if (rode)
+                {
+                    // only the bulk stream ran class-2 work this round; the class-2 stream stays in order behind it
                     if (cstream [2] != cstream [1]) HIP_TRY (hipStreamWaitEvent (cstream [2], evAt [1][r], 0)) ;
                     evAt [2][r] = evAt [1][r] ;
                 }
@@ -889,7 +896,6 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
             if (eng_verbose && rout_calls > 0) fprintf (stderr, "    [engine] of which R hand-off: %d groups, %.2f ms, %d rounds\n", rout_calls, rout_ms, (int) nrounds) ;
             HIP_TRY (hipStreamSynchronize (sCompute)) ;
             HIP_TRY (hipStreamSynchronize (sApply)) ;
-            if (dc->sSmall) HIP_TRY (hipStreamSynchronize (dc->sSmall)) ;
             HIP_TRY (hipStreamSynchronize (sCopy)) ;
             HIP_TRY (hipEventElapsedTime (&ms, evStart, evStop)) ;
             ENG_TICK ("wait for the device") ;
@@ -926,7 +932,6 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
 cleanup:
     (void) hipStreamSynchronize (sCompute) ;
     (void) hipStreamSynchronize (sApply) ;
-    if (dc->sSmall) (void) hipStreamSynchronize (dc->sSmall) ;
     (void) hipStreamSynchronize (sCopy) ;
     for (size_t i = 0 ; i < evProf.size ( ) ; i++) (void) hipEventDestroy (evProf [i]) ;
     if (code != GPUQR_SUCCESS) dc->plan_key = 0 ;
@@ -959,45 +964,29 @@ static uint64_t problem_fingerprint (const gpuqr_front *fronts, int64_t nf)
     return h | 1 ;
 }
 
-static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint64_t plan_key)
+// Everything the launch loops need of one engine call: the tasks, and the workgroups sorted into
+// (round, launch slot) buckets.
+struct Schedule
 {
-    const char *eng_env = getenv ("GPUQR_VERBOSE") ;
-    const bool eng_verbose = eng_env && atoi (eng_env) >= 2 ;
-    double eng_tlast = eng_now_ms ( ) ;
-    int code = GPUQR_SUCCESS ;
-    QrTask *d_tasks = NULL ;
-    QrRef *d_refs = NULL ;
-    double *d_vt = NULL ;
-    hipStream_t sCompute = NULL, sApply = NULL, sCopy = NULL ;
-    hipEvent_t evStart = NULL, evStop = NULL ;
-    DeviceCache *dc = NULL ;
-    int64_t launches = 0 ;
-    float ms = 0 ;
+    Plan plan ;
+    hvec<int32_t> done_last ;       // per front and class: latest round used
+    hvec<int64_t> rptr ;            // first workgroup of every (round, slot) bucket
+    hvec<int32_t> bdep ;            // per bucket and class: latest round depended on
+    hvec<double> bflops, bbytes ;   // per bucket: flops and algorithmic bytes of its tasks
+    int32_t nrounds = 0 ;
+    int64_t nbuckets = 0, ntasks = 0, nrefs = 0 ;
+} ;
 
-    if (stats) { stats->kernelTime = 0 ; stats->numLaunches = 0 ; stats->flopsActual = 0 ; }
-    if (nf <= 0) return GPUQR_SUCCESS ;
-    dc = device_cache ( ) ;
-    if (!dc) return GPUQR_GPUERROR ;
-    LaunchPlan &lp = dc->lp ;
-
-    // Without a key from the caller the engine makes its own from the problem description, so that
-    // a repeated call (same shapes, staircases and buffers, new values) skips planning, sorting and
-    // the upload of the tasks just the same.
-    static int auto_key = -1 ;
-    if (auto_key < 0) auto_key = (getenv ("GPUQR_NO_PLAN_CACHE") == NULL) ? 1 : 0 ;
-    if (plan_key == 0 && auto_key && engine_mode ( ) != 1)
-    {
-        plan_key = problem_fingerprint (fronts, nf) ;
-        ENG_TICK ("fingerprint") ;
-    }
-
-    // The caller vouches, by passing the same nonzero key, that nothing about the problem but the
-    // values in the fronts has changed since the call that left its schedule on the device.
-    if (plan_key != 0 && dc->plan_key == plan_key && dc->plan_nf == nf && engine_mode ( ) != 1 && lp.ntasks > 0)
-        return launch_rounds (dc, fronts, nf, stats, eng_verbose, eng_tlast) ;
-    dc->plan_key = 0 ;          // the device buffers are about to be overwritten
-
-    try
+// Validate the fronts, order them children first, emit their tasks and sort the workgroups by
+// (round, launch slot).  Host work only.
+static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const bool eng_verbose, double &eng_tlast)
+{
+    Plan &plan = sc.plan ;
+    hvec<int32_t> &done_last = sc.done_last, &bdep = sc.bdep ;
+    hvec<int64_t> &rptr = sc.rptr ;
+    hvec<double> &bflops = sc.bflops, &bbytes = sc.bbytes ;
+    int32_t &nrounds = sc.nrounds ;
+    int64_t &nbuckets = sc.nbuckets, &ntasks = sc.ntasks, &nrefs = sc.nrefs ;
     {
         // ---- validate ---------------------------------------------------------------
         for (int64_t f = 0 ; f < nf ; f++)
@@ -1036,9 +1025,9 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
 
         ENG_TICK ("validate + order") ;
         // ---- build the schedule -----------------------------------------------------
-        Plan plan ;
         // per front: latest round of each class that assembled into it; latest round of each class it used
-        hvec<int32_t> in_last ((size_t) nf * QR_NCLASS, -1), done_last ((size_t) nf * QR_NCLASS, -1) ;
+        hvec<int32_t> in_last ((size_t) nf * QR_NCLASS, -1) ;
+        done_last.assign ((size_t) nf * QR_NCLASS, -1) ;
         for (size_t k = 0 ; k < order.size ( ) ; k++)
         {
             const int64_t f = order [k] ;
@@ -1113,11 +1102,11 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
         }
 
         ENG_TICK ("plan") ;
-        const int64_t ntasks = (int64_t) plan.tasks.size ( ) ;
-        int32_t nrounds = 0 ;
+        ntasks = (int64_t) plan.tasks.size ( ) ;
+        nrounds = 0 ;
         for (int64_t i = 0 ; i < ntasks ; i++) nrounds = std::max (nrounds, plan.tasks [i].round + 1) ;
 
-        const int64_t nbuckets = (int64_t) nrounds * QR_NSLOTS ;
+        nbuckets = (int64_t) nrounds * QR_NSLOTS ;
         // An update launch that cannot fill the chip runs as long as one of its workgroups does:
         // there the column blocks are made narrower (more, shorter workgroups).  The threshold is in
         // workgroups per launch; one workgroup slot = half a compute unit.
@@ -1153,9 +1142,9 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
             }
         }
         // counting sort of the workgroups by (round, launch slot): one launch per non-empty bucket
-        hvec<int64_t> rptr ((size_t) nbuckets + 1, 0) ;
+        rptr.assign ((size_t) nbuckets + 1, 0) ;
         // latest round of each class that some task of the bucket depends on
-        hvec<int32_t> bdep ((size_t) nbuckets * QR_NCLASS, -1) ;
+        bdep.assign ((size_t) nbuckets * QR_NCLASS, -1) ;
         for (int64_t i = 0 ; i < ntasks ; i++)
         {
             const SchedTask &st = plan.tasks [i] ;
@@ -1164,8 +1153,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
             for (int c = 0 ; c < QR_NCLASS ; c++) bdep [b*QR_NCLASS + c] = std::max (bdep [b*QR_NCLASS + c], st.dep [c]) ;
         }
         for (int64_t b = 0 ; b < nbuckets ; b++) rptr [b+1] += rptr [b] ;
-        const int64_t nrefs = rptr [nbuckets] ;
-        hvec<double> bflops, bbytes ;       // per bucket, for the per-kernel profile
+        nrefs = rptr [nbuckets] ;
         {
             bflops.assign ((size_t) nbuckets, 0.0) ; bbytes.assign ((size_t) nbuckets, 0.0) ;
             for (int64_t i = 0 ; i < ntasks ; i++)
@@ -1196,6 +1184,84 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
         }
 
         ENG_TICK ("bucket sort") ;
+    }
+    return GPUQR_SUCCESS ;
+}
+
+// Point the panel tasks at their VT tiles, check the bounds the kernels index LDS and registers
+// by, and write the task records and the (task, block) list of the workgroups in launch order.
+static int stage_tasks (Schedule &sc, double *d_vt, QrTask *h_tasks, QrRef *h_refs)
+{
+    hvec<int64_t> pos (sc.rptr) ;
+    for (int64_t i = 0 ; i < sc.ntasks ; i++)
+    {
+        SchedTask &st = sc.plan.tasks [i] ;
+        if (st.t.type == QR_TASK_FACTORIZE || st.t.type == QR_TASK_APPLY)
+        {
+            QrPanelTask &pt = st.t.u.panel ;
+            pt.VT = (st.vt >= 0) ? d_vt + (size_t) st.vt * QR_VT_DOUBLES : NULL ;
+            bool ok = pt.K >= 1 && pt.K <= QR_MAX_K && pt.w >= 1 && pt.w <= QR_PANEL_W
+                && pt.nseg >= 1 && pt.nseg <= QR_MAX_SEG && pt.col0 >= 0 && pt.col0 + pt.w <= pt.ld
+                && (st.t.type == QR_TASK_FACTORIZE || (pt.VT != NULL && pt.c_begin >= 0
+                    && pt.c_begin < pt.c_end && pt.c_end <= pt.ld && pt.cb_cols >= 16
+                    && (int64_t) (st.nblk - 1) * pt.cb_cols < pt.c_end - pt.c_begin)) ;
+            int acc = 0 ;
+            for (int s = 0 ; s < pt.nseg && ok ; s++) { ok = pt.seg_row [s] >= 0 && pt.seg_n [s] >= 1 ; acc += pt.seg_n [s] ; }
+            if (!ok || acc != pt.K) return GPUQR_GPUERROR ;
+        }
+        h_tasks [i] = st.t ;
+        int64_t &q = pos [(int64_t) st.round * QR_NSLOTS + st.slot] ;
+        for (int32_t b = 0 ; b < st.nblk ; b++) { h_refs [q].task = (int32_t) i ; h_refs [q].blk = b ; q++ ; }
+    }
+    return GPUQR_SUCCESS ;
+}
+
+static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint64_t plan_key)
+{
+    const char *eng_env = getenv ("GPUQR_VERBOSE") ;
+    const bool eng_verbose = eng_env && atoi (eng_env) >= 2 ;
+    double eng_tlast = eng_now_ms ( ) ;
+    int code = GPUQR_SUCCESS ;
+    QrTask *d_tasks = NULL ;
+    QrRef *d_refs = NULL ;
+    double *d_vt = NULL ;
+    hipStream_t sCompute = NULL, sApply = NULL, sCopy = NULL ;
+    hipEvent_t evStart = NULL, evStop = NULL ;
+    DeviceCache *dc = NULL ;
+    int64_t launches = 0 ;
+    float ms = 0 ;
+
+    if (stats) { stats->kernelTime = 0 ; stats->numLaunches = 0 ; stats->flopsActual = 0 ; }
+    if (nf <= 0) return GPUQR_SUCCESS ;
+    dc = device_cache ( ) ;
+    if (!dc) return GPUQR_GPUERROR ;
+    LaunchPlan &lp = dc->lp ;
+
+    // Without a key from the caller the engine makes its own from the problem description, so that
+    // a repeated call (same shapes, staircases and buffers, new values) skips planning, sorting and
+    // the upload of the tasks just the same.
+    static int auto_key = -1 ;
+    if (auto_key < 0) auto_key = (getenv ("GPUQR_NO_PLAN_CACHE") == NULL) ? 1 : 0 ;
+    if (plan_key == 0 && auto_key && engine_mode ( ) != 1)
+    {
+        plan_key = problem_fingerprint (fronts, nf) ;
+        ENG_TICK ("fingerprint") ;
+    }
+
+    // The caller vouches, by passing the same nonzero key, that nothing about the problem but the
+    // values in the fronts has changed since the call that left its schedule on the device.
+    if (plan_key != 0 && dc->plan_key == plan_key && dc->plan_nf == nf && engine_mode ( ) != 1 && lp.ntasks > 0)
+        return launch_rounds (dc, fronts, nf, stats, eng_verbose, eng_tlast) ;
+    dc->plan_key = 0 ;          // the device buffers are about to be overwritten
+
+    try
+    {
+        Schedule sc ;
+        code = build_schedule (fronts, nf, sc, eng_verbose, eng_tlast) ;
+        if (code != GPUQR_SUCCESS) return code ;
+        Plan &plan = sc.plan ;
+        hvec<int64_t> &rptr = sc.rptr ;
+        const int64_t ntasks = sc.ntasks, nrefs = sc.nrefs, nbuckets = sc.nbuckets ;
         sCompute = dc->sCompute ; sApply = dc->sApply ; sCopy = dc->sCopy ; evStart = dc->evStart ; evStop = dc->evStop ;
 
         // How launch-bound the schedule is: time of the launches if each ran alone (a launch lasts at
@@ -1229,11 +1295,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
             // different fronts run free of each other.
             const size_t task_bytes = (size_t) ntasks * sizeof (QrTask) ;
             const size_t ref_bytes = (size_t) nrefs * sizeof (QrQueueRef) ;
-#ifdef PQ_STATS
-            const size_t ctr_bytes = ((size_t) (QR_QUEUE_FIRST + std::max<int64_t> (nf, 1100)) * sizeof (int) + 15) & ~(size_t) 15 ;
-#else
             const size_t ctr_bytes = ((size_t) (QR_QUEUE_FIRST + nf) * sizeof (int) + 15) & ~(size_t) 15 ;
-#endif
             HIP_TRY (dc->ensure (&dc->d_vt, &dc->cap_vt, (size_t) plan.n_vt * QR_VT_DOUBLES * sizeof (double), false)) ;
             HIP_TRY (dc->ensure (&dc->d_tasks, &dc->cap_tasks, task_bytes, false)) ;
             HIP_TRY (dc->ensure (&dc->d_refs, &dc->cap_refs, ref_bytes, false)) ;
@@ -1334,16 +1396,6 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
             }
             HIP_TRY (hipStreamSynchronize (sCompute)) ;
             HIP_TRY (hipEventElapsedTime (&ms, evStart, evStop)) ;
-#ifdef PQ_STATS
-            if (nf <= 1000)
-            {
-                unsigned long long st [7] ;
-                HIP_TRY (hipMemcpy (st, (int *) dc->d_counters + 1024, sizeof (st), hipMemcpyDeviceToHost)) ;
-                double tot = (double) st [6] ;
-                fprintf (stderr, "pq stats: kernel %.2f ms; per-WG shares: wait %.1f%% factorize %.1f%% apply %.1f%% assemble %.1f%% publish %.1f%%; tasks %llu, clock ticks per WG %.0f\n",
-                    ms, 100*st [0]/tot, 100*st [1]/tot, 100*st [2]/tot, 100*st [3]/tot, 100*st [4]/tot, st [5], tot / 512) ;
-            }
-#endif
             if (qstate [QR_QUEUE_ERROR] != 0 || qstate [QR_QUEUE_HEAD] < nrefs)
             {
                 if (getenv ("GPUQR_VERBOSE")) fprintf (stderr, "gpuqr: work queue stopped early (error %d, head %d of %ld)\n",
@@ -1363,39 +1415,17 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
             d_vt = (double *) dc->d_vt ; d_tasks = (QrTask *) dc->d_tasks ; d_refs = (QrRef *) dc->d_refs ;
             QrTask *h_tasks = (QrTask *) dc->h_stage ;
             QrRef *h_refs = (QrRef *) ((char *) dc->h_stage + task_bytes) ;
-            {
-                hvec<int64_t> pos (rptr) ;
-                for (int64_t i = 0 ; i < ntasks ; i++)
-                {
-                    SchedTask &st = plan.tasks [i] ;
-                    if (st.t.type == QR_TASK_FACTORIZE || st.t.type == QR_TASK_APPLY)
-                    {
-                        QrPanelTask &pt = st.t.u.panel ;
-                        pt.VT = (st.vt >= 0) ? d_vt + (size_t) st.vt * QR_VT_DOUBLES : NULL ;
-                        // the kernels index LDS and registers by these bounds: check them here
-                        bool ok = pt.K >= 1 && pt.K <= QR_MAX_K && pt.w >= 1 && pt.w <= QR_PANEL_W
-                            && pt.nseg >= 1 && pt.nseg <= QR_MAX_SEG && pt.col0 >= 0 && pt.col0 + pt.w <= pt.ld
-                            && (st.t.type == QR_TASK_FACTORIZE || (pt.VT != NULL && pt.c_begin >= 0
-                                && pt.c_begin < pt.c_end && pt.c_end <= pt.ld && pt.cb_cols >= 16
-                                && (int64_t) (st.nblk - 1) * pt.cb_cols < pt.c_end - pt.c_begin)) ;
-                        int acc = 0 ;
-                        for (int s = 0 ; s < pt.nseg && ok ; s++) { ok = pt.seg_row [s] >= 0 && pt.seg_n [s] >= 1 ; acc += pt.seg_n [s] ; }
-                        if (!ok || acc != pt.K) { code = GPUQR_GPUERROR ; goto cleanup ; }
-                    }
-                    h_tasks [i] = st.t ;
-                    int64_t &q = pos [(int64_t) st.round * QR_NSLOTS + st.slot] ;
-                    for (int32_t b = 0 ; b < st.nblk ; b++) { h_refs [q].task = (int32_t) i ; h_refs [q].blk = b ; q++ ; }
-                }
-            }
+            code = stage_tasks (sc, d_vt, h_tasks, h_refs) ;
+            if (code != GPUQR_SUCCESS) goto cleanup ;
             ENG_TICK ("task + ref staging") ;
             HIP_TRY (hipMemcpyAsync (d_tasks, h_tasks, task_bytes, hipMemcpyHostToDevice, sCompute)) ;
             HIP_TRY (hipMemcpyAsync (d_refs, h_refs, ref_bytes, hipMemcpyHostToDevice, sCompute)) ;
 
             // the schedule is on the device: remember whose it is, then run it
-            lp.rptr.swap (rptr) ; lp.bdep.swap (bdep) ; lp.done_last.swap (done_last) ;
-            lp.nrounds = nrounds ; lp.nbuckets = nbuckets ; lp.ntasks = ntasks ; lp.nrefs = nrefs ; lp.flops = plan.flops ;
+            lp.rptr.swap (sc.rptr) ; lp.bdep.swap (sc.bdep) ; lp.done_last.swap (sc.done_last) ;
+            lp.nrounds = sc.nrounds ; lp.nbuckets = nbuckets ; lp.ntasks = ntasks ; lp.nrefs = nrefs ; lp.flops = plan.flops ;
             dc->plan_key = plan_key ; dc->plan_nf = nf ;
-            lp.bflops.swap (bflops) ; lp.bbytes.swap (bbytes) ;
+            lp.bflops.swap (sc.bflops) ; lp.bbytes.swap (sc.bbytes) ;
             return launch_rounds (dc, fronts, nf, stats, eng_verbose, eng_tlast) ;
         }
         if (stats)
@@ -1413,7 +1443,6 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
 cleanup:
     if (sCompute) (void) hipStreamSynchronize (sCompute) ;
     if (sApply) (void) hipStreamSynchronize (sApply) ;
-    if (dc && dc->sSmall) (void) hipStreamSynchronize (dc->sSmall) ;
     if (sCopy) (void) hipStreamSynchronize (sCopy) ;
     // streams, events and device buffers stay in the per-device cache for the next call
     return code ;

@@ -147,9 +147,6 @@ template <int CTRL> __device__ __forceinline__ double dpp_move (double x)
 // sum over each group of RG neighbouring lanes, result in all of them
 template <int RG> __device__ __forceinline__ double sum_rows (double x)
 {
-#ifdef FACT_NO_REDUCE
-    return x ;
-#endif
     x += dpp_move<0xB1> (x) ;       // quad_perm [1,0,3,2]
     x += dpp_move<0x4E> (x) ;       // quad_perm [2,3,0,1]
     x += dpp_move<0x141> (x) ;      // row_half_mirror: lane i <-> 7-i of each 8
@@ -209,9 +206,6 @@ __device__ __forceinline__ double make_reflector
     //   x1 >  0:  v1 = -sigma/(x1 + s) = -sigma/q,  1/v1 = -q/sigma,  tau = sigma/(q s)
     // and 1/sigma is refined next to 1/sqrt(n2), off the chain.
     double s, tau, inv ;
-#ifdef FACT_NO_SCALAR
-    if (true) { s = x1 ; tau = 0.5 ; inv = sigma ; } else
-#endif
     if (sigma <= HOUSE_EPS)
     {
         s = x1 ; tau = 0 ; inv = 0 ;
@@ -267,9 +261,7 @@ __device__ __forceinline__ void house_steps
             if (k >= kmax) break ;
             const int k1 = k + 1 ;
             const int own1 = (k1 / CPW) & (NW - 1) ;    // the wave that owns column k+1: the critical one
-#ifndef FACT_NO_T
             if (k > 0 && wave == ((own1 + NW/2) & (NW - 1))) t_column (L, k - 1, lane) ;
-#endif
 
             const double *vb = L.vbuf [k & 1] ;
             double v [RPT] ;
@@ -314,21 +306,10 @@ __device__ __forceinline__ void house_steps
     }
 }
 
-#ifdef FACT_STATS
-__device__ unsigned long long g_fact_stats [8] ;
-#define FACT_TICK(i) do { __syncthreads ( ) ; if (threadIdx.x == 0) { unsigned long long now = __builtin_amdgcn_s_memtime ( ) ; \
-    atomicAdd (&g_fact_stats [i], now - tick) ; tick = now ; } } while (0)
-#else
-#define FACT_TICK(i)
-#endif
-
 template <int RPT, int RG>
 __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *smem)
 {
     constexpr int NT = 32 * RG ;                        // threads of the workgroup
-#ifdef FACT_STATS
-    unsigned long long tick = __builtin_amdgcn_s_memtime ( ) ;
-#endif
     FactorizeLds &L = *reinterpret_cast<FactorizeLds *>(smem) ;
     const int tid = threadIdx.x ;
     const int lane = tid & 63 ;
@@ -375,13 +356,10 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
     if (wave == 0 && c == 0) s_cur = make_reflector<RPT, RG> (a, L, 0, 0, rg) ;
     __syncthreads ( ) ;
 
-    FACT_TICK (0) ;
     house_steps<RPT, RG, 0> (a, s_cur, L, kmax, rg, c, wave, lane) ;
-    FACT_TICK (1) ;
     house_steps<RPT, RG, 1> (a, s_cur, L, kmax, rg, c, wave, lane) ;
     house_steps<RPT, RG, 2> (a, s_cur, L, kmax, rg, c, wave, lane) ;
     house_steps<RPT, RG, 3> (a, s_cur, L, kmax, rg, c, wave, lane) ;
-    FACT_TICK (2) ;
 
     // ---- write back R (zeros below the diagonal), V2 in place, V1 to the VT tile ----
     #pragma unroll
@@ -408,7 +386,6 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
             if (pair1) *(gd2 *) p = o ; else p [0] = o.x ;
         }
     }
-    FACT_TICK (3) ;
 
     // ---- T (only when somebody will apply this panel): its last column, then the tile ----
     if (VT != NULL)
@@ -421,7 +398,6 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
             if (cc >= r && r < w && cc < w) VT [r*32 + cc] = L.T [r][cc] ;
         }
     }
-    FACT_TICK (4) ;
 }
 
 // -----------------------------------------------------------------------------
@@ -452,19 +428,11 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
 
 #define VS_LD 34
 
-#ifdef ABL_NOMFMA
-// timing-only build: the matrix instructions are replaced by one add that keeps the operands alive
-#define MFMA64(a, b, c) ((c) + (v4f64) {(a) * (b), 0.0, 0.0, 0.0})
-#else
+// (a micro-benchmark that includes this file may supply its own forms of these three)
+#ifndef MFMA64
 #define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64 ((a), (b), (c), 0, 0, 0)
 #endif
-
-// The trailing matrix streams through once per panel: with ABL_NT its accesses carry the
-// non-temporal hint.
-#ifdef ABL_NT
-#define SLAB_LOAD(p) __builtin_nontemporal_load (p)
-#define SLAB_STORE(v, p) __builtin_nontemporal_store ((v), (p))
-#else
+#ifndef SLAB_LOAD
 #define SLAB_LOAD(p) (*(p))
 #define SLAB_STORE(v, p) (*(p) = (v))
 #endif
@@ -520,11 +488,7 @@ __device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk
             for (int h = 0 ; h < 2 ; h++)
             {
                 const int r = mt*16 + 8*h + l8 ;
-#ifdef ABL_NOMEM
-                A [mt][h] = (d2) {(double) (r + col), 1.0} ;
-#else
                 A [mt][h] = SLAB_LOAD ((gd2 *) (F + (size_t) rowmap [r] * ld + lcol)) ;
-#endif
             }
         }
     }
@@ -630,17 +594,12 @@ __device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk
                 d2 o = {acc [2*h], acc [2*h + 1]} ;
                 o = pair_exchange (o) ;
                 gdouble *rowp = F + (size_t) rowmap [r] * ld ;
-#ifdef ABL_NOMEM
-                if (o.x == 1.2345e-300) rowp [col] = o.y ;
-                A [mt][h] = (d2) {o.x + 1.0, o.y + 1.0} ;
-#else
                 if (r < K)
                 {
                     if (v1)      SLAB_STORE (o, (gd2 *) (rowp + col)) ;
                     else if (v0) rowp [col] = o.x ;
                 }
                 A [mt][h] = SLAB_LOAD ((gd2 *) (rowp + nlcol)) ;
-#endif
             }
         }
     }
@@ -965,15 +924,8 @@ k_persistent (const QrTask *tasks, const QrQueueRef *refs, int nrefs, int *count
     // front of the dynamic array and shift its base)
     int &sh_ticket = *reinterpret_cast<int *>(smem + QR_QUEUE_LDS_TASK_BYTES) ;
     int &sh_ok = *reinterpret_cast<int *>(smem + QR_QUEUE_LDS_TASK_BYTES + 4) ;
-#ifdef PQ_STATS
-    unsigned long long t_wait = 0, t_run [3] = {0, 0, 0}, t_pub = 0, n_run = 0 ;
-    unsigned long long t_begin = __builtin_amdgcn_s_memtime ( ) ;
-#endif
     for ( ; ; )
     {
-#ifdef PQ_STATS
-        unsigned long long s0 = __builtin_amdgcn_s_memtime ( ) ;
-#endif
         __syncthreads ( ) ;         // everybody is done with smem and sh_* of the previous task
         if (threadIdx.x == 0)
         {
@@ -1009,23 +961,7 @@ k_persistent (const QrTask *tasks, const QrQueueRef *refs, int nrefs, int *count
         }
         __syncthreads ( ) ;
         const int q = sh_ticket ;
-#ifdef PQ_STATS
-        unsigned long long s1 = __builtin_amdgcn_s_memtime ( ) ;
-        t_wait += s1 - s0 ;
-        if (q >= nrefs || !sh_ok)
-        {
-            if (threadIdx.x == 0)
-            {
-                unsigned long long *st = (unsigned long long *) (counters + 1024) ;    // diagnostic build: counters has room
-                atomicAdd (st + 0, t_wait) ; atomicAdd (st + 1, t_run [0]) ; atomicAdd (st + 2, t_run [1]) ;
-                atomicAdd (st + 3, t_run [2]) ; atomicAdd (st + 4, t_pub) ; atomicAdd (st + 5, n_run) ;
-                atomicAdd (st + 6, __builtin_amdgcn_s_memtime ( ) - t_begin) ;
-            }
-            return ;
-        }
-#else
         if (q >= nrefs || !sh_ok) return ;          // queue drained, or an error was raised
-#endif
         const QrQueueRef r = refs [q] ;
         const QrTask &t = tasks [r.task] ;
         switch (t.type)
@@ -1058,21 +994,12 @@ k_persistent (const QrTask *tasks, const QrQueueRef *refs, int nrefs, int *count
         // publish: every wave drains its stores, then one lane releases and signals
         asm volatile ("s_waitcnt vmcnt(0)" ::: "memory") ;
         __syncthreads ( ) ;
-#ifdef PQ_STATS
-        unsigned long long s2 = __builtin_amdgcn_s_memtime ( ) ;
-        t_run [t.type == QR_TASK_FACTORIZE ? 0 : (t.type == QR_TASK_APPLY ? 1 : 2)] += s2 - s1 ; n_run++ ;
-#endif
         if (threadIdx.x == 0)
         {
-#ifndef ABL_NOREL
             __builtin_amdgcn_fence (__ATOMIC_RELEASE, "agent") ;
-#endif
             asm volatile ("s_waitcnt vmcnt(0)" ::: "memory") ;
             __hip_atomic_fetch_add (counters + QR_QUEUE_FIRST + r.signal_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
         }
-#ifdef PQ_STATS
-        t_pub += __builtin_amdgcn_s_memtime ( ) - s2 ;
-#endif
     }
 }
 
