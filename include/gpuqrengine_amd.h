@@ -168,6 +168,32 @@ void gpuqr_set_mode (int mode);
  * GPUQREngine/Source/GPUQREngine_Internal.cpp:34-51).  This frees them. */
 void gpuqr_finalize (void);
 
+/* Per-device set-up of what the engine keeps between calls (two compute streams, a copy stream, two
+ * events, kernel attributes, the address of the device's fixed workspace), for the current device.
+ * Every entry point does this by itself on its first call on a device; a caller that must not
+ * allocate inside gpuqr_factor_sparse_noalloc calls it once beforehand.  No counterpart in the
+ * reference, whose Scheduler constructor does the equivalent on every call
+ * (GPUQREngine/Source/Scheduler/Scheduler.cpp:172-253).  Returns GPUQR_SUCCESS or GPUQR_GPUERROR. */
+int gpuqr_init (void);
+
+/* gpuqr_factor_sparse for callers that cannot allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.  Same fronts, same
+ * kernels and same results as gpuqr_factor_sparse (device-resident fronts in gpuF, reduced in
+ * place; R rows copied to cpuR where it is set), but the task records, the workgroup list and the
+ * VT tiles live in a fixed device workspace of gpuqr_noalloc_workspace_bytes() = 32 MiB that is part
+ * of the library's code object (each GPU the library runs on holds it until the process ends), and
+ * the planner's host memory comes from a static 128 MiB block: after gpuqr_init() on the device the
+ * call makes no hipMalloc, hipHostMalloc, hipFree, stream or event creation, and no heap allocation.
+ * It runs on one stream, round after round.  Limits: a batch whose records and VT tiles exceed the
+ * workspace (or whose plan exceeds the host block) is refused with GPUQR_TOOLARGE before anything
+ * is launched (gpuqr_noalloc_last_need() then tells the bytes it would take); fronts that ask for
+ * the packed R hand-off (gpuRpack / cpuRpack) are refused with GPUQR_GPUERROR.  All calls on one GPU
+ * share that GPU's workspace: calls that overlap on one GPU race, also with each other's results. */
+#define GPUQR_TOOLARGE 3
+int gpuqr_factor_sparse_noalloc (gpuqr_front *fronts, int64_t numFronts, gpuqr_stats *stats);
+size_t gpuqr_noalloc_workspace_bytes (void);
+size_t gpuqr_noalloc_last_need (void);
+
 /* Number of HIP devices visible, or 0 (never fails). */
 int gpuqr_device_count (void);
 

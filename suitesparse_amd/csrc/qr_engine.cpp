@@ -62,6 +62,25 @@ extern "C" void gpuqr_set_allocator (void *(*m) (size_t), void *(*c) (size_t, si
     g_free   = f ? f : free ;
 }
 
+// Host arena of the entry point that allocates nothing: while it is switched on, the planner's
+// vectors are carved out of this static block (bump pointer, nothing is given back before the call
+// ends) instead of the heap.  Running out of it is reported like any failed allocation.
+#define GPUQR_HOST_ARENA_BYTES ((size_t) 128 << 20)
+static unsigned char g_host_arena [GPUQR_HOST_ARENA_BYTES] __attribute__ ((aligned (64))) ;
+static size_t g_host_arena_pos = 0 ;
+static bool g_host_arena_on = false ;
+
+static inline bool in_host_arena (const void *p)
+{
+    return (const unsigned char *) p >= g_host_arena && (const unsigned char *) p < g_host_arena + GPUQR_HOST_ARENA_BYTES ;
+}
+
+struct HostArenaScope
+{
+    HostArenaScope ( ) { g_host_arena_pos = 0 ; g_host_arena_on = true ; }
+    ~HostArenaScope ( ) { g_host_arena_on = false ; }
+} ;
+
 // std::vector storage that honours the hooks and reports failure by bad_alloc
 template <class T> struct HookAlloc
 {
@@ -71,11 +90,19 @@ template <class T> struct HookAlloc
     T *allocate (size_t n)
     {
         if (n > (size_t) -1 / sizeof (T)) throw std::bad_alloc ( ) ;
+        if (g_host_arena_on)
+        {
+            const size_t bytes = (n * sizeof (T) + 63) & ~(size_t) 63 ;
+            if (bytes > GPUQR_HOST_ARENA_BYTES - g_host_arena_pos) throw std::bad_alloc ( ) ;
+            void *p = g_host_arena + g_host_arena_pos ;
+            g_host_arena_pos += bytes ;
+            return (T *) p ;
+        }
         void *p = g_malloc (n * sizeof (T)) ;
         if (!p) throw std::bad_alloc ( ) ;
         return (T *) p ;
     }
-    void deallocate (T *p, size_t) { g_free (p) ; }
+    void deallocate (T *p, size_t) { if (!in_host_arena (p)) g_free (p) ; }
     template <class U> bool operator== (const HookAlloc<U> &) const { return true ; }
     template <class U> bool operator!= (const HookAlloc<U> &) const { return false ; }
 } ;
@@ -466,6 +493,8 @@ struct DeviceCache
     void *d_tasks = NULL, *d_refs = NULL, *d_vt = NULL, *h_stage = NULL, *d_counters = NULL, *d_pack = NULL ;
     size_t cap_tasks = 0, cap_refs = 0, cap_vt = 0, cap_stage = 0, cap_counters = 0, cap_pack = 0 ;
     int num_cus = 0 ;
+    char *scratch = NULL ;          // this device's copy of the fixed workspace (hipGetSymbolAddress), never freed
+    size_t scratch_bytes = 0 ;
 
     hipError_t ensure (void **p, size_t *cap, size_t need, bool pinned_host)
     {
@@ -1468,6 +1497,122 @@ extern "C" int gpuqr_factor_sparse
     (void) gpuMemorySize ; (void) Parent ; (void) Childp ; (void) Child ;
     if (numFronts < 0 || (numFronts > 0 && fronts == NULL)) return GPUQR_GPUERROR ;
     return engine_run (fronts, numFronts, stats, 0) ;
+}
+
+// -----------------------------------------------------------------------------
+// the entry point that allocates nothing
+// -----------------------------------------------------------------------------
+
+extern "C" hipError_t qr_scratch_address (void **ptr, size_t *bytes) ;
+
+// Per-device set-up of everything the engine keeps between calls: streams, events, the kernels'
+// attributes, and the address of the device's copy of the fixed workspace.  Whatever must be created
+// is created here, so that gpuqr_factor_sparse_noalloc itself creates nothing.
+extern "C" int gpuqr_init (void)
+{
+    DeviceCache *dc = device_cache ( ) ;
+    if (!dc) return GPUQR_GPUERROR ;
+    if (dc->scratch == NULL)
+    {
+        void *p = NULL ; size_t bytes = 0 ;
+        if (qr_scratch_address (&p, &bytes) != hipSuccess || p == NULL) return GPUQR_GPUERROR ;
+        dc->scratch = (char *) p ;
+        dc->scratch_bytes = bytes ;
+    }
+    return GPUQR_SUCCESS ;
+}
+
+extern "C" size_t gpuqr_noalloc_workspace_bytes (void) { return (size_t) QR_SCRATCH_BYTES ; }
+
+static size_t g_noalloc_need = 0 ;
+extern "C" size_t gpuqr_noalloc_last_need (void) { return g_noalloc_need ; }
+
+extern "C" int gpuqr_factor_sparse_noalloc (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats)
+{
+    if (stats) { stats->kernelTime = 0 ; stats->numLaunches = 0 ; stats->flopsActual = 0 ; }
+    if (nf < 0 || (nf > 0 && fronts == NULL)) return GPUQR_GPUERROR ;
+    if (nf == 0) return GPUQR_SUCCESS ;
+    // first call on this device: set-up (a caller that must not allocate even then calls gpuqr_init before)
+    if (gpuqr_init ( ) != GPUQR_SUCCESS) return GPUQR_GPUERROR ;
+    DeviceCache *dc = device_cache ( ) ;
+    // the packed R hand-off needs a task list of its own on the device: not offered here
+    for (int64_t f = 0 ; f < nf ; f++) if (fronts [f].gpuRpack != NULL || fronts [f].cpuRpack != NULL) return GPUQR_GPUERROR ;
+
+    int code = GPUQR_SUCCESS ;
+    hipStream_t stream = dc->sCompute ;
+    bool eng_verbose = false ; double eng_tlast = 0 ;
+    g_noalloc_need = 0 ;
+    HostArenaScope arena ;      // from here on the planner's vectors come out of the static host block
+    try
+    {
+        Schedule sc ;
+        code = build_schedule (fronts, nf, sc, eng_verbose, eng_tlast) ;
+        if (code != GPUQR_SUCCESS) return code ;
+        if (sc.ntasks > 0)
+        {
+            const size_t task_bytes = ((size_t) sc.ntasks * sizeof (QrTask) + 255) & ~(size_t) 255 ;
+            const size_t ref_bytes = ((size_t) sc.nrefs * sizeof (QrRef) + 255) & ~(size_t) 255 ;
+            const size_t vt_bytes = (size_t) sc.plan.n_vt * QR_VT_DOUBLES * sizeof (double) ;
+            g_noalloc_need = task_bytes + ref_bytes + vt_bytes ;
+            if (g_noalloc_need > dc->scratch_bytes)
+            {
+                if (getenv ("GPUQR_VERBOSE")) fprintf (stderr, "gpuqr_factor_sparse_noalloc: the batch needs %zu bytes of "
+                    "workspace, the fixed workspace holds %zu\n", g_noalloc_need, dc->scratch_bytes) ;
+                return GPUQR_TOOLARGE ;
+            }
+            // dc->scratch is the address hipGetSymbolAddress gave for this device
+            QrTask *d_tasks = (QrTask *) dc->scratch ;
+            QrRef *d_refs = (QrRef *) (dc->scratch + task_bytes) ;
+            double *d_vt = (double *) (dc->scratch + task_bytes + ref_bytes) ;
+            hvec<QrTask> h_tasks ((size_t) sc.ntasks) ;
+            hvec<QrRef> h_refs ((size_t) std::max<int64_t> (sc.nrefs, 1)) ;
+            code = stage_tasks (sc, d_vt, h_tasks.data ( ), h_refs.data ( )) ;
+            if (code != GPUQR_SUCCESS) return code ;
+            // Nothing in the workspace has to start at zero: every word a kernel reads from it was
+            // written earlier in this call (the records by these copies, a VT tile by the panel task
+            // in front of the updates that read it).
+            HIP_TRY (hipMemcpyAsync (d_tasks, h_tasks.data ( ), (size_t) sc.ntasks * sizeof (QrTask), hipMemcpyHostToDevice, stream)) ;
+            HIP_TRY (hipMemcpyAsync (d_refs, h_refs.data ( ), (size_t) sc.nrefs * sizeof (QrRef), hipMemcpyHostToDevice, stream)) ;
+            HIP_TRY (hipEventRecord (dc->evStart, stream)) ;
+            // one stream, rounds in order: a task of round r reads only what rounds < r wrote
+            int64_t launches = 0 ;
+            for (int32_t r = 0 ; r < sc.nrounds ; r++)
+            {
+                for (int slot = 0 ; slot < QR_NSLOTS ; slot++)
+                {
+                    const int64_t b = (int64_t) r * QR_NSLOTS + slot ;
+                    const int64_t n = sc.rptr [b+1] - sc.rptr [b] ;
+                    if (n <= 0) continue ;
+                    HIP_TRY (qr_launch_tasks (slot_kernel (slot), d_tasks, d_refs + sc.rptr [b], (int) n, stream)) ;
+                    launches++ ;
+                }
+            }
+            HIP_TRY (hipEventRecord (dc->evStop, stream)) ;
+            for (int64_t f = 0 ; f < nf ; f++)
+            {
+                gpuqr_front &fr = fronts [f] ;
+                if (fr.cpuR == NULL || (fr.is_sparse && fr.push_only)) continue ;
+                int64_t nrows = fr.rank ;
+                if (fr.is_sparse && fr.is_staged) nrows += fr.cm ;
+                if (nrows > fr.fm) nrows = fr.fm ;
+                HIP_TRY (pull_rows (fr, nrows, stream)) ;
+            }
+            HIP_TRY (hipStreamSynchronize (stream)) ;
+            float ms = 0 ;
+            HIP_TRY (hipEventElapsedTime (&ms, dc->evStart, dc->evStop)) ;
+            if (stats) { stats->kernelTime = ms ; stats->numLaunches = launches ; }
+        }
+        if (stats) stats->flopsActual = sc.plan.flops ;
+    }
+    catch (std::bad_alloc &)
+    {
+        // the static host block ran out: the batch is too large for the fixed workspaces
+        code = GPUQR_TOOLARGE ;
+    }
+
+cleanup:
+    (void) hipStreamSynchronize (stream) ;
+    return code ;
 }
 
 // -----------------------------------------------------------------------------

@@ -1051,6 +1051,41 @@ extern "C" hipError_t qr_launch_tasks (int kid, const QrTask *d_tasks, const QrR
     return qr_launch_tasks_timed (kid, d_tasks, d_refs, nrefs, stream, NULL, NULL) ;
 }
 
+// -----------------------------------------------------------------------------
+// fixed workspace of the entry point that allocates nothing
+// -----------------------------------------------------------------------------
+//
+// gpuqr_factor_sparse_noalloc keeps what the other entry points put in hipMalloc'd buffers (the
+// task records, the workgroup list and the VT tiles) in this array.  Every GPU the library runs on
+// holds its own copy, at its own address, until the process ends.  In host code the array's name
+// is only a handle for hipGetSymbolAddress: the address kernels and copies must use is the one
+// that call returns, looked up once per device with that device current.
+
+static __device__ __align__(256) unsigned char scratch [QR_SCRATCH_BYTES] ;
+
+#define QR_SCRATCH_MAX_DEVICES 64
+static void *g_scratch_ptr [QR_SCRATCH_MAX_DEVICES] ;
+
+// Device address of the current device's copy of the workspace, and its size.
+extern "C" hipError_t qr_scratch_address (void **ptr, size_t *bytes)
+{
+    int dev = -1 ;
+    hipError_t e = hipGetDevice (&dev) ;
+    if (e != hipSuccess) return e ;
+    if (dev < 0 || dev >= QR_SCRATCH_MAX_DEVICES) return hipErrorInvalidDevice ;
+    if (g_scratch_ptr [dev] == NULL)
+    {
+        void *p = NULL ;
+        e = hipGetSymbolAddress ((void **) &p, HIP_SYMBOL (scratch)) ;
+        if (e != hipSuccess) return e ;
+        if (p == NULL) return hipErrorInvalidSymbol ;
+        g_scratch_ptr [dev] = p ;
+    }
+    *ptr = g_scratch_ptr [dev] ;
+    *bytes = QR_SCRATCH_BYTES ;
+    return hipSuccess ;
+}
+
 extern "C" hipError_t qr_kernels_init (void)
 {
     // dynamic LDS above 64 KB needs an explicit opt-in on HIP

@@ -20,6 +20,7 @@
 #define QR_VT_DOUBLES     1024  // one VT tile: 32x32 doubles (T upper, V1 strictly lower)
 #define QR_SASM_CHUNK     2048  // S entries scattered by one S-assembly task
 #define QR_PACK_TILE      128   // contribution-block tile edge of one pack-assembly task
+#define QR_SCRATCH_BYTES  (32u << 20)   // fixed device workspace of the entry point that allocates nothing
 
 enum QrTaskType
 {
