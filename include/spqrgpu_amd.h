@@ -100,6 +100,7 @@ typedef struct spqr_amd_numeric
     double  *Cstack;        /* subset driver: contribution blocks leaving this process (compact cm-by-cn) */
     int64_t *Cblock;        /* subset driver: size nf, offset of front f's block in Cstack or -1 */
     int64_t  RstackPinned;  /* 1: Rstack is pinned host memory; 0: the pinned allocation was refused and it is pageable */
+    int64_t  csize;         /* subset driver: doubles of contribution blocks that left (in Cstack or the caller's device buffer) */
 } spqr_amd_numeric;
 
 /* Replaces void spqrgpu_kernel (spqr_blob <double> *Blob)
@@ -138,6 +139,19 @@ int spqr_amd_rconvert_blocks (const spqr_amd_symbolic *sym, const double *Rstack
 int spqrgpu_amd_factorize_subset (const spqr_amd_symbolic *sym, const int64_t *Ap, const int64_t *Ai,
                                   const double *Ax, const char *mine, const double *const *limbo_in,
                                   spqr_amd_numeric **num_out);
+
+/* The same with the contribution blocks on the device on both sides, for the exchange between GPUs
+ * (RCCL send/recv or peer copies straight on these buffers; no counterpart in the reference, whose
+ * limbo blocks cross host memory, spqrgpu_kernel.cpp:598-603,711-723).  limbo_in_dev[c] is a device
+ * address on the current device and the block is assembled from where it lies; the blocks that leave
+ * are written to c_out_dev, which has room for spqrgpu_amd_subset_csize (sym, mine) doubles, at
+ * num->Cblock[f] (compact cm-by-cn, row-major; entries below the diagonal are unspecified and never
+ * read).  num->Cstack stays NULL. */
+int spqrgpu_amd_factorize_subset_dev (const spqr_amd_symbolic *sym, const int64_t *Ap, const int64_t *Ai,
+                                      const double *Ax, const char *mine,
+                                      const double *const *limbo_in_dev, double *c_out_dev,
+                                      spqr_amd_numeric **num_out);
+int64_t spqrgpu_amd_subset_csize (const spqr_amd_symbolic *sym, const char *mine);
 
 #ifdef __cplusplus
 }

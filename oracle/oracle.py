@@ -155,3 +155,58 @@ def front_qr_batch(mats, nthreads=1):
     t0 = time.perf_counter()
     f(_p(F), _p(fm), _p(fn), len(mats), nthreads)
     return time.perf_counter() - t0
+
+
+def multifrontal_lapack(sym, Sx, keep_R=True):
+    """CPU multifrontal QR with the fronts factorized by LAPACK's blocked Householder QR (dgeqrf:
+    dlarfg / dlarft / dlarfb, the routines the reference's CPU path is built from,
+    SPQR/Source/spqr_front.cpp:141-154,402-408, spqr_larftb.cpp:48-83) on the threaded BLAS the host
+    has.  Fronts in postorder, one at a time, as spqr_kernel does without TBB
+    (SPQR/Source/spqr_kernel.cpp:134-321); assembly through the same maps as the device path.  Unlike
+    spqr_front it does not skip the zeros under the staircase.  Returns (R blocks: front -> rank x fn
+    upper-trapezoidal array, or None when keep_R is False; seconds spent in dgeqrf; seconds in all)."""
+    import time
+    from scipy.linalg import lapack
+    nf = sym.nf
+    t_all = time.perf_counter()
+    Stair, Rjmap, Rimap, cpuS = build_assembly_maps(sym, Sx)
+    post = _i64(sym.Post)[:nf]
+    Scount = np.array([sym.Sp[sym.Sleft[sym.Super[f + 1]]] - sym.Sp[sym.Sleft[sym.Super[f]]] for f in range(nf)],
+                      dtype=np.int64)
+    SOff = np.zeros(nf + 1, np.int64)
+    SOff[post] = np.concatenate([[0], np.cumsum(Scount[post])[:-1]]) if nf > 0 else 0
+    Cblk = {}
+    Rb = {} if keep_R else None
+    t_qr = 0.0
+    for f in post:
+        f = int(f)
+        fm, fn, fp = int(sym.Fm[f]), int(sym.Rp[f + 1] - sym.Rp[f]), int(sym.Super[f + 1] - sym.Super[f])
+        F = np.zeros((fm, fn), order="F")          # column-major, as LAPACK wants it
+        e = cpuS[SOff[f]:SOff[f] + Scount[f]]
+        if fn > 0:
+            F[e["findex"] // fn, e["findex"] % fn] = e["value"]
+        for c in sym.Child[sym.Childp[f]:sym.Childp[f + 1]]:
+            c = int(c)
+            Cc = Cblk.pop(c, None)
+            if Cc is None or Cc.size == 0:
+                continue
+            cm, cn = Cc.shape
+            ri = Rimap[sym.RimapOffsets[c]:sym.RimapOffsets[c] + cm]
+            rj = Rjmap[sym.RjmapOffsets[c]:sym.RjmapOffsets[c] + cn]
+            # a parent row takes exactly one child row, whose entries left of the diagonal are zero
+            F[np.ix_(ri, rj)] = Cc
+        rk = min(fm, fp)
+        if fm > 0 and fn > 0:
+            t0 = time.perf_counter()
+            lw, info = lapack.dgeqrf_lwork(fm, fn)      # the blocked code needs its full workspace
+            qr, tau, work, info = lapack.dgeqrf(F, lwork=max(int(lw), 1), overwrite_a=True)
+            t_qr += time.perf_counter() - t0
+            assert info == 0
+        else:
+            qr = F
+        if keep_R:
+            Rb[f] = np.triu(qr[:rk])
+        cm, cn = int(sym.Cm[f]), fn - fp
+        if int(sym.Parent[f]) < nf and cm * cn > 0:
+            Cblk[f] = np.triu(qr[rk:rk + cm, fp:])
+    return Rb, t_qr, time.perf_counter() - t_all

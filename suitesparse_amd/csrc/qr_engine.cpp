@@ -81,6 +81,11 @@ struct HostArenaScope
     ~HostArenaScope ( ) { g_host_arena_on = false ; }
 } ;
 
+// the hooks for the other translation units of the library
+extern "C" void *qr_host_malloc (size_t bytes) { return g_malloc (bytes) ; }
+extern "C" void *qr_host_calloc (size_t n, size_t size) { return g_calloc (n, size) ; }
+extern "C" void  qr_host_free (void *p) { g_free (p) ; }
+
 // std::vector storage that honours the hooks and reports failure by bad_alloc
 template <class T> struct HookAlloc
 {

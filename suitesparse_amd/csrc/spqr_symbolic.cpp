@@ -225,6 +225,7 @@ extern "C" spqr_amd_symbolic *spqr_amd_analyze
             // fpc * (fpc + fnp) - (entries of the child's R block).
             std::vector<Long> fp (nf), fnn (nf), rnz (nf) ;
             std::vector<char> dead (nf, 0) ;
+            const Long big_pivots = 256 ;
             for (Long f = 0 ; f < nf ; f++)
             {
                 fp [f] = super [f+1] - super [f] ;
@@ -244,6 +245,11 @@ extern "C" spqr_amd_symbolic *spqr_amd_analyze
                 const Long mrnz = mfp * mfn - mfp * (mfp - 1) / 2 ;
                 const Long old = rnz [f] + rnz [p] ;
                 const bool small = (mfp <= 4) ;
+                // Two fronts that are each wide enough to fill the device gain nothing from becoming
+                // one, and the tree loses a branch that could have run beside its siblings (on another
+                // GPU, or in the same launches): they stay apart whatever the zero count says.
+                const bool both_big = (fp [f] >= big_pivots && fp [p] >= big_pivots) ;
+                if (both_big) continue ;
                 if (small || (double) (mrnz - old) <= (double) relax * 0.01 * (double) mrnz)
                 {
                     dead [f] = 1 ;

@@ -7,6 +7,30 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <vector>
+#include <new>
+
+// host memory through the engine's allocator hooks (qr_engine.cpp)
+extern "C" void *qr_host_malloc (size_t bytes) ;
+extern "C" void *qr_host_calloc (size_t n, size_t size) ;
+extern "C" void  qr_host_free (void *p) ;
+
+template <class T> struct HostAlloc
+{
+    typedef T value_type ;
+    HostAlloc ( ) { }
+    template <class U> HostAlloc (const HostAlloc<U> &) { }
+    T *allocate (size_t n)
+    {
+        if (n > (size_t) -1 / sizeof (T)) throw std::bad_alloc ( ) ;
+        void *p = qr_host_malloc (n * sizeof (T)) ;
+        if (!p) throw std::bad_alloc ( ) ;
+        return (T *) p ;
+    }
+    void deallocate (T *p, size_t) { qr_host_free (p) ; }
+    template <class U> bool operator== (const HostAlloc<U> &) const { return true ; }
+    template <class U> bool operator!= (const HostAlloc<U> &) const { return false ; }
+} ;
+template <class T> using hostvec = std::vector<T, HostAlloc<T> > ;
 
 struct spqr_amd_symbolic
 {
@@ -26,9 +50,10 @@ struct spqr_amd_symbolic
     {
         bool built = false ;
         int  device = -1 ;                  // the device that holds the d_* copies
-        std::vector<int64_t> Stair ;        // per front, at Rp [f]
-        std::vector<int32_t> Rimap, Rjmap ;
-        std::vector<int64_t> SGlob ;        // first packed S entry of front f (entries in postorder of fronts)
+        uint64_t pattern = 0 ;              // fingerprint of the Ap / Ai the cache was built from
+        hostvec<int64_t> Stair ;            // per front, at Rp [f]
+        hostvec<int32_t> Rimap, Rjmap ;
+        hostvec<int64_t> SGlob ;            // first packed S entry of front f (entries in postorder of fronts)
         void *d_Rimap = NULL, *d_Rjmap = NULL ;
         void *d_findex = NULL ;             // int64 per S entry: where it goes in its front
         void *d_aperm = NULL ;              // int64 per S entry: position of its value in the caller's Ax

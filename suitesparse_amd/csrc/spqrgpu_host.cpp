@@ -16,6 +16,13 @@
 
 typedef int64_t Long ;
 
+// Host memory comes from the engine's allocator hooks (gpuqr_set_allocator), as the reference takes
+// all of its own from SuiteSparse_config's table, so that a failing allocator installed by a test
+// reaches every allocation of the glue too.
+static inline void *host_malloc (size_t bytes) { return qr_host_malloc (bytes) ; }
+static inline void *host_calloc (size_t n, size_t size) { return qr_host_calloc (n, size) ; }
+static inline void host_free (void *p) { if (p) qr_host_free (p) ; }
+
 // -----------------------------------------------------------------------------
 // staging
 // -----------------------------------------------------------------------------
@@ -243,21 +250,34 @@ static void release_numeric_cache (spqr_amd_symbolic::NumericCache *c)
 // symbolic object and device.  Runs the restated spqrgpu_buildAssemblyMaps with the position of
 // each entry in place of its value, which gives the permutation from the caller's Ax to packed S.
 // Returns 0, 1 (out of memory) or 2 (device error).
+static uint64_t pattern_fingerprint (const int64_t *Ap, const int64_t *Ai, Long n, Long anz)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t) n ;
+    for (Long k = 0 ; k <= n ; k++) { h = (h ^ (uint64_t) Ap [k]) * 0xff51afd7ed558ccdull ; h ^= h >> 32 ; }
+    for (Long k = 0 ; k < anz ; k++) { h = (h ^ (uint64_t) Ai [k]) * 0xff51afd7ed558ccdull ; h ^= h >> 32 ; }
+    return h ;
+}
+
 static int build_numeric_cache (const spqr_amd_symbolic *S, const int64_t *Ap, const int64_t *Ai)
 {
     spqr_amd_symbolic::NumericCache &C = S->cache ;
     int dev = -1 ;
     if (hipGetDevice (&dev) != hipSuccess) return 2 ;
-    if (C.built && C.device == dev) return 0 ;
+    if (Ap [S->n] != S->anz) return 3 ;             // not the matrix that was analysed
+    // The cache is derived from the pattern of the first matrix factorized with this object: a later
+    // call with another pattern (same size or not) must not reuse it silently.
+    const uint64_t fp = pattern_fingerprint (Ap, Ai, S->n, S->anz) ;
+    if (C.built && C.device == dev && C.pattern == fp) return 0 ;
     if (C.built) release_numeric_cache (&C) ;
+    C.pattern = fp ;
     C.release = release_numeric_cache ;
     const Long nf = S->nf, n = S->n, m = S->m, anz = S->anz ;
     const Long *Sp = S->Sp.data ( ), *Super = S->Super.data ( ), *Sleft = S->Sleft.data ( ), *Post = S->Post.data ( ) ;
     // position in Ax of every entry of S = A(P,Q) in row form (spqr_stranspose2's scatter)
-    std::vector<Long> sxperm ((size_t) std::max ((Long) 1, anz)) ;
-    std::vector<double> Sx ((size_t) std::max ((Long) 1, anz)) ;
+    hostvec<Long> sxperm ((size_t) std::max ((Long) 1, anz)) ;
+    hostvec<double> Sx ((size_t) std::max ((Long) 1, anz)) ;
     {
-        std::vector<Long> w (Sp, Sp + m) ;
+        hostvec<Long> w (Sp, Sp + m) ;
         for (Long k = 0 ; k < n ; k++)
         {
             const Long col = S->Qfill [k] ;
@@ -268,12 +288,12 @@ static int build_numeric_cache (const spqr_amd_symbolic *S, const int64_t *Ap, c
     const Long RimapSize = std::max ((Long) 1, S->RimapSize), RjmapSize = std::max ((Long) 1, S->RjmapSize) ;
     C.Stair.assign ((size_t) std::max ((Long) 1, S->Rp [nf]), 0) ;
     C.Rimap.assign ((size_t) RimapSize, 0) ; C.Rjmap.assign ((size_t) RjmapSize, 0) ;
-    std::vector<Long> Fmap ((size_t) std::max ((Long) 1, n)) ;
-    std::vector<gpuqr_sentry> allS ((size_t) std::max ((Long) 1, anz)) ;
+    hostvec<Long> Fmap ((size_t) std::max ((Long) 1, n)) ;
+    hostvec<gpuqr_sentry> allS ((size_t) std::max ((Long) 1, anz)) ;
     spqrgpu_amd_build_assembly_maps (nf, n, Fmap.data ( ), Post, Super, S->Rp.data ( ), S->Rj.data ( ), Sleft, Sp,
         S->Sj.data ( ), Sx.data ( ), S->Fm.data ( ), S->Cm.data ( ), S->Childp.data ( ), S->Child.data ( ), C.Stair.data ( ),
         C.Rjmap.data ( ), S->RjmapOffsets.data ( ), C.Rimap.data ( ), S->RimapOffsets.data ( ), allS.data ( )) ;
-    std::vector<Long> findex ((size_t) std::max ((Long) 1, anz)), aperm ((size_t) std::max ((Long) 1, anz)) ;
+    hostvec<Long> findex ((size_t) std::max ((Long) 1, anz)), aperm ((size_t) std::max ((Long) 1, anz)) ;
     for (Long k = 0 ; k < anz ; k++) { findex [k] = allS [k].findex ; aperm [k] = sxperm [(Long) allS [k].value] ; }
     C.SGlob.assign ((size_t) nf + 1, 0) ;
     {
@@ -304,9 +324,9 @@ static int build_numeric_cache (const spqr_amd_symbolic *S, const int64_t *Ap, c
 extern "C" void spqr_amd_numeric_free (spqr_amd_numeric *num)
 {
     if (!num) return ;
-    if (num->Rstack) { if (num->RstackPinned) (void) hipHostFree (num->Rstack) ; else free (num->Rstack) ; }
-    free (num->Rblock) ; free (num->Rdead) ; free (num->Cstack) ; free (num->Cblock) ;
-    free (num) ;
+    if (num->Rstack) { if (num->RstackPinned) (void) hipHostFree (num->Rstack) ; else host_free (num->Rstack) ; }
+    host_free (num->Rblock) ; host_free (num->Rdead) ; host_free (num->Cstack) ; host_free (num->Cblock) ;
+    host_free (num) ;
 }
 
 // Grow-only device / pinned buffer
@@ -389,27 +409,40 @@ extern "C" void spqrgpu_amd_finalize (void)
 }
 
 // The numeric factorization of a set of fronts, group by group.  Mirrors
-// spqrgpu_kernel.cpp:63-782: build S and the maps, then per group (a stage of
-// the staging, or one process's share of the tree) zero the front arena, ship
-// S, describe the fronts (plus push-only fronts for contribution blocks that
-// come from outside the group), run the engine, and hand R back.
+// spqrgpu_kernel.cpp:63-782: build S and the maps, then per group zero the
+// front arena, ship S, describe the fronts (plus push-only fronts for
+// contribution blocks that come from outside the group), run the engine, and
+// hand R back.
+//
+// Groups.  mine == NULL: all fronts, one group per stage of the staging.
+// mine != NULL (one process's share of the tree): the fronts with mine[f] != 0,
+// cut into groups that fit the declared device memory the way the staging cuts
+// the whole tree (in postorder, a group is closed when the next front with the
+// blocks it needs from outside no longer fits; gpuMemorySize = 0 puts every
+// front in a group of its own).
+//
+// Contribution blocks.  A block whose parent is factorized by a later group of
+// this call waits in limbo: on the device when it has the room, on the host
+// otherwise.  A block whose parent is not in this call at all leaves through
+// c_out_dev (device, compact cm-by-cn, at Cblock[f]) or, when that is NULL,
+// num->Cstack (host).  A block that arrives from outside the call comes from
+// limbo_in[c]: a device address used where it lies (limbo_in_dev), or host
+// memory that is copied in.
 //
 // Device layout of a group, chosen here (the staging's FOffsets price the memory
 // but do not bind the placement): fronts one after another in postorder, each
 // with its rows padded to an even length so that every row starts on a 16-byte
-// boundary, each followed by the compact contribution blocks of its children
-// from outside the group.  R never visits the host unpacked: a kernel writes
-// the column-packed upper trapezoids of all fronts of the group into one
-// device block laid out like the final stack, and a single DMA moves that block
-// into the pinned Rstack.
-//
-// mine == NULL: all fronts, groups = stages, blocks leaving a stage wait in host
-// limbo.  mine != NULL: one group of the fronts with mine[f] != 0, blocks
-// arriving from limbo_in, blocks leaving through num->Cstack.
+// boundary, each followed by the compact contribution blocks of those children
+// whose blocks have to be copied in.  The arenas are sized for the largest group
+// before the first one runs, so that blocks waiting on the device can never be
+// in the way of a later, larger arena.  R never visits the host unpacked: a kernel
+// writes the column-packed upper trapezoids of all fronts of the group into one
+// device block laid out like the final stack.
 static int factorize_impl
 (
     const spqr_amd_symbolic *S, const int64_t *Ap, const int64_t *Ai, const double *Ax,
-    const char *mine, const double *const *limbo_in, spqr_amd_numeric **num_out
+    const char *mine, const double *const *limbo_in, const bool limbo_in_dev, double *c_out_dev,
+    spqr_amd_numeric **num_out
 )
 {
     *num_out = NULL ;
@@ -420,33 +453,34 @@ static int factorize_impl
     const Long *Super = S->Super.data ( ), *Rp = S->Rp.data ( ), *Post = S->Post.data ( ) ;
     const Long *Parent = S->Parent.data ( ), *Childp = S->Childp.data ( ), *Child = S->Child.data ( ) ;
     const Long *Fm = S->Fm.data ( ), *Cm = S->Cm.data ( ), *Sleft = S->Sleft.data ( ), *Sp = S->Sp.data ( ) ;
-    const Long *StageMap = S->StageMap.data ( ), *Stagingp = S->Stagingp.data ( ) ;
 
-    spqr_amd_numeric *num = (spqr_amd_numeric *) calloc (1, sizeof (spqr_amd_numeric)) ;
+    spqr_amd_numeric *num = (spqr_amd_numeric *) host_calloc (1, sizeof (spqr_amd_numeric)) ;
     if (!num) return 1 ;
     // device workspaces live in a per-device cache between calls: allocating and freeing tens of
     // gigabytes costs seconds (5-6 s per call at 96^3), far more than anything else on the host side
     int wdev = 0 ;
-    if (hipGetDevice (&wdev) != hipSuccess || wdev < 0 || wdev >= MAX_WS_DEVICES) { free (num) ; return 2 ; }
+    if (hipGetDevice (&wdev) != hipSuccess || wdev < 0 || wdev >= MAX_WS_DEVICES) { host_free (num) ; return 2 ; }
     Workspaces &WS = g_ws [wdev] ;
     Buf &dF = WS.dF, &dS = WS.dS, &dAx = WS.dAx, &dTasks = WS.dTasks, &dPrefix = WS.dPrefix ;
-    // A pageable R stack is filled through bounce buffers; between stages that copy runs on a thread of
-    // its own beside the next stage, which then packs its R into the other of two device blocks.
+    // A pageable R stack is filled through bounce buffers; between groups that copy runs on a thread of
+    // its own beside the next group, which then packs its R into the other of two device blocks.
     std::thread r_thread ;
     hipError_t r_thread_err = hipSuccess ;
     auto join_r = [&] ( ) { if (r_thread.joinable ( )) r_thread.join ( ) ; return r_thread_err ; } ;
-    std::vector<gpuqr_front> fronts ;
-    std::vector<double *> limbo ;           // contribution blocks waiting on the host for a later stage
-    std::vector<double *> limbo_dev ;       // ... or on the device, when it has the room (no PCIe round trip)
-    std::vector<double *> used_dev ;        // device limbo blocks consumed by the running stage
+    hostvec<gpuqr_front> fronts ;
+    hostvec<double *> limbo ;           // contribution blocks waiting on the host for a later group
+    hostvec<double *> limbo_dev ;       // ... or on the device, when it has the room (no PCIe round trip)
+    hostvec<double *> used_dev ;        // device limbo blocks consumed by the running group
 
     try
     {
         if (!mine && S->numStages <= 0 && nf > 0) { code = 2 ; goto done ; }
+        if (mine && S->gpuMemorySize == 1 && nf > 0) { code = 2 ; goto done ; }    // the "nothing fits" test value
 
         // ---- what this call factorizes, and the size of its R ------------------------------
         auto S_count = [&] (Long f) { return std::max ((Long) 0, Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]]) ; } ;
         auto is_mine = [&] (Long f) { return mine == NULL || mine [f] != 0 ; } ;
+        auto c_size = [&] (Long c) { return Cm [c] * ((Rp [c+1] - Rp [c]) - (Super [c+1] - Super [c])) ; } ;
         Long rtotal = 0, ctotal = 0 ;
         for (Long f = 0 ; f < nf ; f++)
         {
@@ -464,85 +498,155 @@ static int factorize_impl
         {
             (void) hipGetLastError ( ) ;
             num->RstackPinned = 0 ;
-            num->Rstack = (double *) malloc ((size_t) std::max ((Long) 1, rtotal) * sizeof (double)) ;
+            num->Rstack = (double *) host_malloc ((size_t) std::max ((Long) 1, rtotal) * sizeof (double)) ;
             if (!num->Rstack) { code = 1 ; goto done ; }
         }
-        num->Rblock = (Long *) malloc ((size_t) std::max ((Long) 1, nf) * sizeof (Long)) ;
-        num->Rdead = (char *) calloc ((size_t) std::max ((Long) 1, n), 1) ;
+        num->Rblock = (Long *) host_malloc ((size_t) std::max ((Long) 1, nf) * sizeof (Long)) ;
+        num->Rdead = (char *) host_calloc ((size_t) std::max ((Long) 1, n), 1) ;
         if (!num->Rblock || !num->Rdead) { code = 1 ; goto done ; }
         for (Long f = 0 ; f < nf ; f++) num->Rblock [f] = -1 ;
         if (mine)
         {
-            num->Cstack = (double *) calloc ((size_t) std::max ((Long) 1, ctotal), sizeof (double)) ;
-            num->Cblock = (Long *) malloc ((size_t) std::max ((Long) 1, nf) * sizeof (Long)) ;
-            if (!num->Cstack || !num->Cblock) { code = 1 ; goto done ; }
+            if (!c_out_dev)
+            {
+                num->Cstack = (double *) host_calloc ((size_t) std::max ((Long) 1, ctotal), sizeof (double)) ;
+                if (!num->Cstack) { code = 1 ; goto done ; }
+            }
+            num->Cblock = (Long *) host_malloc ((size_t) std::max ((Long) 1, nf) * sizeof (Long)) ;
+            if (!num->Cblock) { code = 1 ; goto done ; }
             for (Long f = 0 ; f < nf ; f++) num->Cblock [f] = -1 ;
         }
+        num->csize = ctotal ;
 
         TICK ("allocation") ;
         // ---- maps, staircases, S pattern: once per symbolic object; this call's values of A ------
         {
-            const int cc = build_numeric_cache (S, Ap, Ai) ;
+            const int cc = build_numeric_cache (S, Ap, Ai) ;        // (a failed host allocation inside it lands in the catch below)
             if (cc != 0) { code = cc ; goto done ; }
         }
         const spqr_amd_symbolic::NumericCache &NC = S->cache ;
-        const std::vector<Long> &Stair = NC.Stair ;
-        const std::vector<Long> &SGlob = NC.SGlob ;
+        const hostvec<Long> &Stair = NC.Stair ;
+        const hostvec<Long> &SGlob = NC.SGlob ;
         TICK ("maps + S pattern (cached)") ;
         if (dAx.ensure ((size_t) std::max ((Long) 1, S->anz) * sizeof (double)) != hipSuccess) { code = 1 ; goto done ; }
         if (S->anz > 0) HIPCHK (hipMemcpyAsync (dAx.p, Ax, (size_t) S->anz * sizeof (double), hipMemcpyHostToDevice, 0)) ;
 
         limbo.assign ((size_t) std::max ((Long) 1, nf), (double *) NULL) ;
         limbo_dev.assign ((size_t) std::max ((Long) 1, nf), (double *) NULL) ;
-        std::vector<Long> rel ((size_t) std::max ((Long) 1, nf), -1), pitch ((size_t) std::max ((Long) 1, nf), 0) ;
+        hostvec<Long> rel ((size_t) std::max ((Long) 1, nf), -1), pitch ((size_t) std::max ((Long) 1, nf), 0) ;
         for (Long f = 0 ; f < nf ; f++) { const Long fn = Rp [f+1] - Rp [f] ; pitch [f] = fn + (fn & 1) ; }
 
-        const Long ngroups = mine ? 1 : S->numStages ;
-        Long rhead = 0, chead = 0 ;
-        // With a page-locked stack the engine itself packs R and sends it (GPUQR_LATE_R: afterwards, in one copy)
-        const bool r_in_engine = num->RstackPinned && getenv ("GPUQR_LATE_R") == NULL ;
-        std::vector<Long> list, FOff, SOff, ROff ;
-        std::vector<PackRTask> ptasks ;
-        std::vector<long long> prefix ;
-        for (Long g = 0 ; g < ngroups ; g++)
+        // ---- groups ------------------------------------------------------------------------------
+        hostvec<Long> grp ((size_t) std::max ((Long) 1, nf), -1) ;
+        Long ngroups = 0 ;
+        if (!mine)
         {
-            // ---- fronts of the group, in postorder -----------------------------------------
-            list.clear ( ) ;
-            if (mine) { for (Long k = 0 ; k < nf ; k++) if (mine [Post [k]]) list.push_back (Post [k]) ; }
-            else for (Long p = Stagingp [g] ; p < Stagingp [g+1] ; p++) list.push_back (Post [p]) ;
-            const Long numFronts = (Long) list.size ( ) ;
-            if (numFronts == 0) { if (!mine) num->numStagesRun++ ; continue ; }
-            auto in_group = [&] (Long f) { return f < nf && (mine ? (mine [f] != 0) : (StageMap [f] == g)) ; } ;
+            for (Long f = 0 ; f < nf ; f++) grp [f] = S->StageMap [f] ;
+            ngroups = S->numStages ;
+        }
+        else
+        {
+            // what the staging reserves outside the front arena (spqrgpu_computeFrontStaging.cpp:90-118)
+            size_t mem = S->gpuMemorySize ;
+            const size_t reserve [4] = { 2 * gpuqr_max_queue_size (mem) * 104, (size_t) S->RimapSize * sizeof (int),
+                (size_t) S->RjmapSize * sizeof (int), (size_t) 1024 * 1024 } ;
+            for (int k = 0 ; k < 4 ; k++) if (mem > 1) mem = (mem > reserve [k]) ? (mem - reserve [k]) : 0 ;
+            size_t acc = 0 ;
+            Long g = 0 ;
+            bool open = false ;
+            for (Long k = 0 ; k < nf ; k++)
+            {
+                const Long f = Post [k] ;
+                if (!mine [f]) continue ;
+                const Long fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
+                size_t need = (size_t) (Fm [f] * pitch [f]) * 8 + (size_t) S_count (f) * 16
+                    + (size_t) r_block_size (fn, std::min (Fm [f], fp)) * 8 + (size_t) (((Fm [f] + 31) / 32) * 1024) * 8 ;
+                size_t kids_here = 0 ;      // blocks of children in the open group: they would have to be copied in
+                for (Long cp = Childp [f] ; cp < Childp [f+1] ; cp++)
+                {
+                    const Long c = Child [cp] ;
+                    if (!(mine [c] && grp [c] == g && open)) need += (size_t) c_size (c) * 8 ;
+                    else kids_here += (size_t) c_size (c) * 8 ;
+                }
+                if (open && (S->gpuMemorySize == 0 || acc + need >= mem))
+                {
+                    g++ ; acc = 0 ; need += kids_here ;
+                }
+                grp [f] = g ; acc += need ; open = true ;
+            }
+            ngroups = open ? g + 1 : 0 ;
+        }
 
-            // ---- layout ---------------------------------------------------------------------
+        // ---- layout of a group --------------------------------------------------------------------
+        hostvec<Long> list, FOff, SOff, ROff ;
+        Long fsum = 0, ssum = 0, rsum = 0, nlimbo = 0 ;
+        auto in_group = [&] (Long f, Long g) { return f < nf && grp [f] == g ; } ;
+        // a child's block is used where it lies when it waits on the device, copied behind its parent otherwise
+        auto child_in_place = [&] (Long c) { return (mine && !mine [c]) ? limbo_in_dev : (limbo_dev [c] != NULL) ; } ;
+        auto layout_group = [&] (Long g, bool final_pass)
+        {
+            list.clear ( ) ;
+            if (mine) { for (Long k = 0 ; k < nf ; k++) if (grp [Post [k]] == g) list.push_back (Post [k]) ; }
+            else for (Long p = S->Stagingp [g] ; p < S->Stagingp [g+1] ; p++) list.push_back (Post [p]) ;
+            const Long numFronts = (Long) list.size ( ) ;
             FOff.assign ((size_t) numFronts, 0) ; SOff.assign ((size_t) numFronts, 0) ; ROff.assign ((size_t) numFronts, 0) ;
-            Long fsum = 0, ssum = 0, rsum = 0, nlimbo = 0 ;
+            fsum = ssum = rsum = nlimbo = 0 ;
             for (Long k = 0 ; k < numFronts ; k++)
             {
                 const Long f = list [k] ;
-                rel [f] = k ;
+                if (final_pass) rel [f] = k ;
                 const Long fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
                 FOff [k] = fsum ; SOff [k] = ssum ; ROff [k] = rsum ;
                 fsum += Fm [f] * pitch [f] ;
                 for (Long cp = Childp [f] ; cp < Childp [f+1] ; cp++)
                 {
                     const Long c = Child [cp] ;
-                    if (in_group (c)) continue ;
+                    if (in_group (c, g)) continue ;
                     nlimbo++ ;
-                    fsum += Cm [c] * ((Rp [c+1] - Rp [c]) - (Super [c+1] - Super [c])) ;
+                    // (the sizing pass cannot know yet which blocks will find room on the device: it
+                    // prices every one of them as copied in)
+                    if (final_pass && child_in_place (c)) continue ;
+                    fsum += c_size (c) ;
                     fsum += (fsum & 1) ;
                 }
                 ssum += S_count (f) ;
                 rsum += r_block_size (fn, std::min (Fm [f], fp)) ;
             }
-            if (dF.ensure ((size_t) std::max ((Long) 1, fsum) * sizeof (double)) != hipSuccess) { code = 1 ; goto done ; }
-            if (dS.ensure ((size_t) std::max ((Long) 1, ssum) * sizeof (gpuqr_sentry)) != hipSuccess) { code = 1 ; goto done ; }
-            Buf &dR = (!num->RstackPinned && ngroups > 1 && (g & 1)) ? WS.dR2 : WS.dR ;
-            if (dR.ensure ((size_t) std::max ((Long) 1, rsum) * sizeof (double)) != hipSuccess) { code = 1 ; goto done ; }
+        } ;
+
+        // ---- arenas sized for the largest group, once ---------------------------------------------
+        const bool two_r = !num->RstackPinned && ngroups > 1 ;
+        {
+            Long fmax = 1, smax = 1, rmax [2] = {1, 1} ;
+            for (Long g = 0 ; g < ngroups ; g++)
+            {
+                layout_group (g, false) ;
+                fmax = std::max (fmax, fsum) ; smax = std::max (smax, ssum) ;
+                Long &rm = rmax [(two_r && (g & 1)) ? 1 : 0] ;
+                rm = std::max (rm, rsum) ;
+            }
+            if (dF.ensure ((size_t) fmax * sizeof (double)) != hipSuccess) { code = 1 ; goto done ; }
+            if (dS.ensure ((size_t) smax * sizeof (gpuqr_sentry)) != hipSuccess) { code = 1 ; goto done ; }
+            if (WS.dR.ensure ((size_t) rmax [0] * sizeof (double)) != hipSuccess) { code = 1 ; goto done ; }
+            if (two_r && WS.dR2.ensure ((size_t) rmax [1] * sizeof (double)) != hipSuccess) { code = 1 ; goto done ; }
+        }
+        TICK ("workspace allocation") ;
+
+        Long rhead = 0, chead = 0 ;
+        // With a page-locked stack the engine itself packs R and sends it (GPUQR_LATE_R: afterwards, in one copy)
+        const bool r_in_engine = num->RstackPinned && getenv ("GPUQR_LATE_R") == NULL ;
+        hostvec<PackRTask> ptasks ;
+        hostvec<long long> prefix ;
+        for (Long g = 0 ; g < ngroups ; g++)
+        {
+            // ---- fronts of the group, in postorder -----------------------------------------
+            layout_group (g, true) ;
+            const Long numFronts = (Long) list.size ( ) ;
+            if (numFronts == 0) { num->numStagesRun++ ; continue ; }
+            Buf &dR = (two_r && (g & 1)) ? WS.dR2 : WS.dR ;
             double *F0 = (double *) dF.p ;
             gpuqr_sentry *S0 = (gpuqr_sentry *) dS.p ;
             fronts.assign ((size_t) (numFronts + nlimbo), gpuqr_front ( )) ;
-            TICK ("workspace allocation") ;
 
             HIPCHK (hipMemsetAsync (F0, 0, (size_t) std::max ((Long) 1, fsum) * sizeof (double), 0)) ;
             // S entries of the group, built on the device; runs of fronts that are neighbours in
@@ -564,7 +668,7 @@ static int factorize_impl
                 const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
                 const Long frank = std::min (fm, fp) ;
                 const Long pid = Parent [f] ;
-                const bool parent_here = in_group (pid) ;
+                const bool parent_here = in_group (pid, g) ;
 
                 gpuqr_front &fr = fronts [k] ;
                 memset (&fr, 0, sizeof (fr)) ;
@@ -595,17 +699,18 @@ static int factorize_impl
                 }
                 else if (pid < nf)
                 {
-                    fr.is_staged = 1 ;      // the parent is factorized in a later stage or elsewhere
+                    fr.is_staged = 1 ;      // the parent is factorized in a later group or elsewhere
                 }
 
-                // children from outside the group: their compact C blocks sit right behind the front
+                // children from outside the group
                 Long child_off = FOff [k] + fm * pitch [f] ;
                 for (Long cp = Childp [f] ; cp < Childp [f+1] ; cp++)
                 {
                     const Long c = Child [cp] ;
-                    if (in_group (c)) continue ;
+                    if (in_group (c, g)) continue ;
                     const Long ccn = (Rp [c+1] - Rp [c]) - (Super [c+1] - Super [c]) ;
                     const Long ccm = Cm [c] ;
+                    const bool external = mine && !mine [c] ;
                     gpuqr_front &ch = fronts [next_child] ;
                     memset (&ch, 0, sizeof (ch)) ;
                     ch.fids = next_child ; ch.pids = k ; ch.fidg = c ; ch.pidg = f ;
@@ -614,28 +719,39 @@ static int factorize_impl
                     ch.pn = (int32_t) pitch [f] ; ch.cm = (int32_t) ccm ; ch.cn = (int32_t) ccn ;
                     ch.gpuRimap = (int32_t *) NC.d_Rimap + S->RimapOffsets [c] ;
                     ch.gpuRjmap = (int32_t *) NC.d_Rjmap + S->RjmapOffsets [c] ;
-                    ch.gpuF = ch.gpuC = F0 + child_off ;
-                    if (ccm * ccn > 0 && !mine && limbo_dev [c])
+                    const bool in_place = child_in_place (c) ;
+                    if (in_place && external)
+                    {
+                        // the caller's device block (it arrived over the fabric, or an earlier call left it)
+                        double *src = (limbo_in && ccm * ccn > 0) ? (double *) limbo_in [c] : NULL ;
+                        if (ccm * ccn > 0 && !src) { code = 3 ; goto done ; }
+                        ch.gpuF = ch.gpuC = src ? src : F0 ;
+                    }
+                    else if (in_place)
                     {
                         // the block never left the device: assemble straight from where it waits
                         ch.gpuF = ch.gpuC = limbo_dev [c] ;
                         used_dev.push_back (limbo_dev [c]) ;
                         limbo_dev [c] = NULL ;
                     }
-                    else if (ccm * ccn > 0)
+                    else
                     {
-                        const double *src = mine ? (limbo_in ? limbo_in [c] : NULL) : limbo [c] ;
-                        if (!src) { code = mine ? 3 : 2 ; goto done ; }
-                        HIPCHK (hipMemcpy (ch.gpuF, src, (size_t) (ccm * ccn) * sizeof (double), hipMemcpyHostToDevice)) ;
+                        ch.gpuF = ch.gpuC = F0 + child_off ;
+                        if (ccm * ccn > 0)
+                        {
+                            const double *src = external ? (limbo_in ? limbo_in [c] : NULL) : limbo [c] ;
+                            if (!src) { code = external ? 3 : 2 ; goto done ; }
+                            HIPCHK (hipMemcpy (ch.gpuF, src, (size_t) (ccm * ccn) * sizeof (double), hipMemcpyHostToDevice)) ;
+                        }
+                        if (!external) { host_free (limbo [c]) ; limbo [c] = NULL ; }
+                        child_off += ccm * ccn ;
+                        child_off += (child_off & 1) ;
                     }
-                    if (!mine) { free (limbo [c]) ; limbo [c] = NULL ; }
-                    child_off += ccm * ccn ;
-                    child_off += (child_off & 1) ;
                     next_child++ ;
                 }
             }
             HIPCHK (hipStreamSynchronize (0)) ;
-            TICK ("stage setup (memset, S, fronts)") ;
+            TICK ("group setup (memset, S, fronts)") ;
 
             // ---- the device work ---------------------------------------------------------------
             gpuqr_stats stats ;
@@ -710,22 +826,34 @@ static int factorize_impl
                 rhead += rsum ;
             }
             {
-                // contribution blocks that leave the group: compact cm-by-cn, zero below the diagonal
+                // contribution blocks that leave the group: compact cm-by-cn
                 for (Long k = 0 ; k < numFronts ; k++)
                 {
                     if (!fronts [k].is_staged) continue ;
                     const Long f = list [k] ;
                     const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
                     const Long frank = std::min (fm, fp) ;
-                    const Long cn = fn - fp, cm = mine ? Cm [f] : std::min (fm - frank, cn) ;
+                    const Long cn = fn - fp ;
+                    const bool leaves_call = mine && !mine [Parent [f]] ;
+                    const Long cm = leaves_call ? Cm [f] : std::min (fm - frank, cn) ;
+                    const double *Csrc = fronts [k].gpuF + frank * pitch [f] + fp ;
                     double *L ;
-                    if (mine) { L = num->Cstack + chead ; num->Cblock [f] = chead ; chead += Cm [f] * cn ; }
+                    if (leaves_call && c_out_dev)
+                    {
+                        // to the caller's device buffer; what lies below the diagonal is never read by an assembly
+                        num->Cblock [f] = chead ;
+                        if (cm > 0 && cn > 0)
+                            HIPCHK (hipMemcpy2DAsync (c_out_dev + chead, (size_t) cn * sizeof (double), Csrc,
+                                (size_t) pitch [f] * sizeof (double), (size_t) cn * sizeof (double), (size_t) cm, hipMemcpyDeviceToDevice, 0)) ;
+                        chead += cm * cn ;
+                        continue ;
+                    }
+                    else if (leaves_call) { L = num->Cstack + chead ; num->Cblock [f] = chead ; chead += cm * cn ; }
                     else if (cm > 0 && cn > 0 && getenv ("GPUQR_HOST_LIMBO") == NULL
                         && hipMalloc ((void **) &limbo_dev [f], (size_t) (cm * cn) * sizeof (double)) == hipSuccess)
                     {
-                        // room on the device: the block waits there (what lies below its diagonal is
-                        // never read by the assembly, so it is not cleared)
-                        HIPCHK (hipMemcpy2DAsync (limbo_dev [f], (size_t) cn * sizeof (double), fronts [k].gpuF + frank * pitch [f] + fp,
+                        // room on the device: the block waits there
+                        HIPCHK (hipMemcpy2DAsync (limbo_dev [f], (size_t) cn * sizeof (double), Csrc,
                             (size_t) pitch [f] * sizeof (double), (size_t) cn * sizeof (double), (size_t) cm, hipMemcpyDeviceToDevice, 0)) ;
                         continue ;
                     }
@@ -733,13 +861,13 @@ static int factorize_impl
                     {
                         (void) hipGetLastError ( ) ;
                         limbo_dev [f] = NULL ;
-                        L = (double *) calloc ((size_t) std::max ((Long) 1, cm * cn), sizeof (double)) ;
+                        L = (double *) host_calloc ((size_t) std::max ((Long) 1, cm * cn), sizeof (double)) ;
                         if (!L) { code = 1 ; goto done ; }
                         limbo [f] = L ;
                     }
                     if (cm > 0 && cn > 0)
                     {
-                        HIPCHK (hipMemcpy2D (L, (size_t) cn * sizeof (double), fronts [k].gpuF + frank * pitch [f] + fp,
+                        HIPCHK (hipMemcpy2D (L, (size_t) cn * sizeof (double), Csrc,
                             (size_t) pitch [f] * sizeof (double), (size_t) cn * sizeof (double), (size_t) cm, hipMemcpyDeviceToHost)) ;
                         for (Long i = 1 ; i < cm ; i++) for (Long j = 0 ; j < std::min (i, cn) ; j++) L [i*cn + j] = 0 ;
                     }
@@ -778,7 +906,7 @@ static int factorize_impl
 
 done:
     if (join_r ( ) != hipSuccess && code == 0) code = 2 ;
-    for (size_t i = 0 ; i < limbo.size ( ) ; i++) free (limbo [i]) ;
+    for (size_t i = 0 ; i < limbo.size ( ) ; i++) host_free (limbo [i]) ;
     for (size_t i = 0 ; i < limbo_dev.size ( ) ; i++) if (limbo_dev [i]) (void) hipFree (limbo_dev [i]) ;
     for (size_t i = 0 ; i < used_dev.size ( ) ; i++) (void) hipFree (used_dev [i]) ;
     if (code != 0) { spqr_amd_numeric_free (num) ; return code ; }
@@ -793,8 +921,8 @@ extern "C" int spqrgpu_amd_factorize
     spqr_amd_numeric **num_out
 )
 {
-    if (!S || !Ap || !Ax || !num_out) return 3 ;
-    return factorize_impl (S, Ap, Ai, Ax, NULL, NULL, num_out) ;
+    if (!S || !Ap || !Ax || !num_out || (!Ai && S->anz > 0)) return 3 ;
+    return factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, num_out) ;
 }
 
 // R blocks -> compressed-column R (the R-only part of spqr_rcount / spqr_rconvert,
@@ -810,8 +938,8 @@ extern "C" int spqr_amd_rconvert_blocks
     if (!S || !Rstack || !Rblock || !Rdead || !Rcp) return 3 ;
     const Long nf = S->nf, n = S->n ;
     const bool fill = (Ri != NULL && Rx != NULL) ;
-    std::vector<Long> next ;
-    if (fill) next.assign (Rcp, Rcp + n) ;
+    hostvec<Long> next ;
+    if (fill) { try { next.assign (Rcp, Rcp + n) ; } catch (std::bad_alloc &) { return 1 ; } }
     else for (Long j = 0 ; j <= n ; j++) Rcp [j] = 0 ;
     Long row1 = 0 ;
     for (Long f = 0 ; f < nf ; f++)
@@ -852,18 +980,46 @@ extern "C" int spqr_amd_rconvert
 // subtree driver: one process's share of the assembly tree
 // -----------------------------------------------------------------------------
 
-// Factorize the fronts f with mine[f] != 0 in one stage on the current device.
-// Children of those fronts that belong to somebody else arrive as compact
-// cm-by-cn contribution blocks in limbo_in[c] (host); fronts whose parent
-// belongs to somebody else leave theirs in num->Cstack at Cblock[f].  This is
-// the reference's stage / limbo mechanism (spqrgpu_kernel.cpp:556-611,687-724)
-// with "a later stage" generalised to "another process".
+// Factorize the fronts f with mine[f] != 0 on the current device (in as many groups as the declared
+// device memory asks for).  Children of those fronts that belong to somebody else arrive as compact
+// cm-by-cn contribution blocks in limbo_in[c] (host); fronts whose parent belongs to somebody else
+// leave theirs in num->Cstack at Cblock[f].  This is the reference's stage / limbo mechanism
+// (spqrgpu_kernel.cpp:556-611,687-724) with "a later stage" generalised to "another process".
 extern "C" int spqrgpu_amd_factorize_subset
 (
     const spqr_amd_symbolic *S, const int64_t *Ap, const int64_t *Ai, const double *Ax,
     const char *mine, const double *const *limbo_in, spqr_amd_numeric **num_out
 )
 {
-    if (!S || !Ap || !Ax || !mine || !num_out) return 3 ;
-    return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in, num_out) ;
+    if (!S || !Ap || !Ax || !mine || !num_out || (!Ai && S->anz > 0)) return 3 ;
+    return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in, false, NULL, num_out) ;
+}
+
+// The same with the contribution blocks staying on the device on both sides: limbo_in[c] are device
+// addresses on the current device (a block received from another GPU, or left by an earlier call),
+// used where they lie; the blocks that leave are written to c_out_dev (device, room for
+// spqrgpu_amd_subset_csize doubles) at Cblock[f].  Nothing crosses host memory.
+extern "C" int spqrgpu_amd_factorize_subset_dev
+(
+    const spqr_amd_symbolic *S, const int64_t *Ap, const int64_t *Ai, const double *Ax,
+    const char *mine, const double *const *limbo_in_dev, double *c_out_dev, spqr_amd_numeric **num_out
+)
+{
+    if (!S || !Ap || !Ax || !mine || !num_out || (!Ai && S->anz > 0)) return 3 ;
+    if (!c_out_dev && spqrgpu_amd_subset_csize (S, mine) > 0) return 3 ;
+    return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in_dev, true, c_out_dev, num_out) ;
+}
+
+// Doubles of contribution blocks that leave a subset call: the fronts of the subset whose parent is
+// not in it.
+extern "C" int64_t spqrgpu_amd_subset_csize (const spqr_amd_symbolic *S, const char *mine)
+{
+    if (!S || !mine) return -1 ;
+    Long total = 0 ;
+    for (Long f = 0 ; f < S->nf ; f++)
+    {
+        if (!mine [f] || S->Parent [f] >= S->nf || mine [S->Parent [f]]) continue ;
+        total += S->Cm [f] * ((S->Rp [f+1] - S->Rp [f]) - (S->Super [f+1] - S->Super [f])) ;
+    }
+    return total ;
 }

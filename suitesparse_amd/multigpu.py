@@ -1,9 +1,11 @@
-"""Sparse QR across the GPUs of one node: independent subtrees of the assembly tree go to
-different ranks, the fronts above the cut are factorized on rank 0, and the contribution
-blocks of the subtree roots travel to rank 0 by point-to-point transfers (RCCL over xGMI with
-the nccl backend, gloo on CPUs).  The single-GPU reference has no counterpart; this is its
-stage / limbo hand-off (SPQR/SPQRGPU/spqrgpu_kernel.cpp:556-611,687-724) with "a later stage"
-replaced by "another GPU".  One process per GPU, launched by torch.distributed.run.
+"""Sparse QR across the GPUs of one node: the assembly tree is mapped onto the ranks
+proportionally (every subtree gets a share of the ranks that matches its share of the flops, a
+front whose subtree spans several ranks is factorized by the first of them), every rank
+factorizes its fronts level by level, and the only data that crosses ranks are contribution
+blocks, point to point, device to device (RCCL over xGMI with the nccl backend; gloo on CPUs).
+The single-GPU reference has no counterpart; this is its stage / limbo hand-off
+(SPQR/SPQRGPU/spqrgpu_kernel.cpp:556-611,687-724) with "a later stage" replaced by "another GPU".
+One process per GPU, launched by torch.distributed.run.
 """
 import ctypes as C
 
@@ -22,105 +24,126 @@ def front_weights(sym):
     return 4.0 * k * fm * fn - 2.0 * k * k * (fm + fn) + (4.0 / 3.0) * k ** 3 + 1.0
 
 
-def partition_subtrees(sym, nparts, oversplit=4):
-    """Cut the assembly tree into subtrees and deal them to `nparts` ranks.
+def _children(sym, f):
+    return [int(c) for c in sym.Child[sym.Childp[f]:sym.Childp[f + 1]]]
 
-    Start from the roots; repeatedly replace the heaviest subtree by its children (its root joins
-    the "top" set kept on rank 0) while there are fewer subtrees than ranks or the heaviest one
-    outweighs a rank's fair share of what is left below the cut (never beyond `oversplit * nparts`
-    subtrees); then assign subtrees to ranks, heaviest first, each to the least loaded rank (the
-    top set is charged to rank 0 first).  Returns (owner, top): owner[f] = rank, top[f] = bool.
+
+def map_tree(sym, nparts):
+    """Proportional mapping of the assembly tree onto `nparts` ranks.
+
+    A forest with a list of ranks is split in two: the ranks in halves, the subtrees into two bins
+    whose weights match the halves (heaviest first, each to the bin that is further below its
+    share).  A single subtree with several ranks gives its root to the first of them and splits its
+    children over all of them; a forest with one rank goes to that rank whole.  A subtree so heavy
+    that it would unbalance any two bins keeps all the ranks, and its light siblings are dealt to the
+    least loaded ranks afterwards.
+
+    Returns (owner, level): owner[f] = rank that factorizes front f; level[f] = number of times the
+    owner changes on the longest path from a leaf up to f.  The fronts (r, L) with owner r and level L
+    form one call of the subset driver on rank r; a call needs blocks only from calls of lower levels.
     """
     nf = sym.nf
     w = front_weights(sym)
-    Childp, Child, Parent = sym.Childp, sym.Child, sym.Parent
+    Parent = sym.Parent
     sub = w.copy()
     for f in range(nf):                         # fronts are in postorder: children before parents
         p = Parent[f]
         if p < nf:
             sub[p] += sub[f]
-    top = np.zeros(nf, dtype=bool)
     owner = np.zeros(nf, dtype=np.int64)
-    if nparts <= 1 or nf == 0:
-        return owner, top
-    roots = [int(c) for c in Child[Childp[nf]:Childp[nf + 1]]]
-    subtrees = list(roots)
-    while len(subtrees) < oversplit * nparts:
-        subtrees.sort(key=lambda f: sub[f])
-        below = sum(sub[f] for f in subtrees)
-        if len(subtrees) >= nparts and sub[subtrees[-1]] <= 1.1 * below / nparts:
-            break
-        pick = None
-        for f in reversed(subtrees):
-            if Childp[f + 1] > Childp[f]:
-                pick = f
-                break
-        if pick is None:
-            break
-        subtrees.remove(pick)
-        top[pick] = True
-        subtrees += [int(c) for c in Child[Childp[pick]:Childp[pick + 1]]]
-    load = np.zeros(nparts)
-    load[0] = w[top].sum()
-    root_owner = {}
-    for f in sorted(subtrees, key=lambda f: -sub[f]):
-        r = int(np.argmin(load))
-        root_owner[f] = r
+    level = np.zeros(nf, dtype=np.int64)
+    if nf == 0:
+        return owner, level
+    load = np.zeros(max(nparts, 1))
+
+    def whole(f, r):
+        stack = [f]
+        while stack:
+            g = stack.pop()
+            owner[g] = r
+            stack.extend(_children(sym, g))
         load[r] += sub[f]
-    # propagate ownership down the subtrees (parents have larger indices than children)
-    own = np.full(nf, -1, dtype=np.int64)
-    for f in subtrees:
-        own[f] = root_owner[f]
-    for f in range(nf - 1, -1, -1):
-        if top[f]:
-            own[f] = 0
-        elif own[f] < 0:
-            own[f] = own[Parent[f]]
-    return own, top
+
+    def forest(kids, ranks):
+        work = [(list(kids), list(ranks))]
+        while work:
+            kids, ranks = work.pop()
+            if not kids:
+                continue
+            if len(ranks) == 1:
+                for k in kids:
+                    whole(k, ranks[0])
+                continue
+            kids.sort(key=lambda k: -sub[k])
+            total = sum(sub[k] for k in kids)
+            n1 = (len(ranks) + 1) // 2
+            share1 = total * n1 / len(ranks)
+            if len(kids) == 1 or sub[kids[0]] > 1.25 * share1:
+                # one subtree carries the forest: its root goes to the first rank, its children
+                # get all the ranks; light siblings are packed onto the least loaded ranks later
+                head, rest = kids[0], kids[1:]
+                owner[head] = ranks[0]
+                load[ranks[0]] += w[head]
+                work.append((_children(sym, head), ranks))
+                late.extend((k, ranks) for k in rest)
+                continue
+            bins = ([], [])
+            fill = [0.0, 0.0]
+            want = [share1, total - share1]
+            for k in kids:
+                b = 0 if (want[0] - fill[0]) >= (want[1] - fill[1]) else 1
+                bins[b].append(k)
+                fill[b] += sub[k]
+            work.append((bins[0], ranks[:n1]))
+            work.append((bins[1], ranks[n1:]))
+
+    late = []
+    roots = _children(sym, nf)
+    forest(roots, list(range(max(nparts, 1))))
+    while late:
+        k, ranks = late.pop()
+        r = min(ranks, key=lambda q: load[q])
+        whole(k, r)
+    for f in range(nf):
+        for c in _children(sym, f):
+            level[f] = max(level[f], level[c] + (1 if owner[c] != owner[f] else 0))
+    return owner, level
 
 
-def gpu_factor_subset(sym, A, mine, limbo):
-    """Default backend: spqrgpu_amd_factorize_subset on the current HIP device.
-    Returns (Rblocks, Cblocks): dicts front -> packed R block / compact C block."""
-    import scipy.sparse as sp
-    L = spqr._bind()
-    A = sp.csc_matrix(A)
-    A.sort_indices()
-    Ap = np.ascontiguousarray(A.indptr, dtype=np.int64)
-    Ai = np.ascontiguousarray(A.indices, dtype=np.int64)
-    Ax = np.ascontiguousarray(A.data, dtype=np.float64)
+def mapping_report(sym, owner, level, nparts):
+    """What the mapping promises, from the flop weights alone: the share of the flops in fronts whose
+    subtree spans several ranks (factorized by one GPU while others may idle), and the speed-up bound
+    total / critical path when every rank runs its calls in level order and a call starts once the
+    calls it takes blocks from have ended."""
     nf = sym.nf
-    mine_c = np.ascontiguousarray(mine, dtype=np.int8)
-    ptrs = (C.c_void_p * max(nf, 1))()
-    keep = []
-    for c, blk in limbo.items():
-        b = np.ascontiguousarray(blk, dtype=np.float64)
-        keep.append(b)
-        ptrs[c] = b.ctypes.data
-    out = C.POINTER(spqr.Numeric)()
-    L.spqrgpu_amd_factorize_subset.restype = C.c_int
-    L.spqrgpu_amd_factorize_subset.argtypes = [C.c_void_p] * 6 + [C.POINTER(C.POINTER(spqr.Numeric))]
-    code = L.spqrgpu_amd_factorize_subset(sym._h, Ap.ctypes.data, Ai.ctypes.data, Ax.ctypes.data,
-                                          mine_c.ctypes.data, C.cast(ptrs, C.c_void_p), C.byref(out))
-    if code != 0:
-        raise RuntimeError("spqrgpu_amd_factorize_subset failed with code %d" % code)
-    num = out.contents
-    Rblocks, Cblocks = {}, {}
-    fm = sym.Fm
-    fnn = np.diff(sym.Rp)
-    fpp = np.diff(sym.Super)
-    for f in np.nonzero(mine_c)[0]:
-        rk = min(int(fm[f]), int(fpp[f]))
-        size = rk * (rk + 1) // 2 + rk * (int(fnn[f]) - rk)
-        off = num.Rblock[f]
-        Rblocks[int(f)] = np.ctypeslib.as_array(num.Rstack, shape=(max(num.rsize, 1),))[off:off + size].copy()
-        coff = num.Cblock[f]
-        if coff >= 0:
-            csz = int(sym.Cm[f]) * (int(fnn[f]) - int(fpp[f]))
-            Cblocks[int(f)] = np.ctypeslib.as_array(num.Cstack, shape=(max(coff + csz, 1),))[coff:coff + csz].copy()
-    stats = dict(kernel_ms=float(num.gpuKernelTime), flops=int(num.gpuFlops), launches=int(num.gpuNumKernelLaunches))
-    L.spqr_amd_numeric_free(out)
-    return Rblocks, Cblocks, stats
+    w = front_weights(sym)
+    total = float(w.sum())
+    if nf == 0 or total <= 0:
+        return dict(top_flops_share=0.0, speedup_bound=1.0, loads=[0.0] * nparts)
+    spans = np.zeros(nf, dtype=bool)            # subtree of f holds fronts of another owner
+    for f in range(nf):
+        for c in _children(sym, f):
+            if spans[c] or owner[c] != owner[f]:
+                spans[f] = True
+    nlev = int(level.max()) + 1
+    cost = np.zeros((nparts, nlev))
+    np.add.at(cost, (owner, level), w)
+    # call (r, L) starts when (r, L-1) has ended and every call that hands it a block has ended
+    need = {}
+    for f in range(nf):
+        p = sym.Parent[f]
+        if p < nf and (owner[p] != owner[f] or level[p] != level[f]):
+            need.setdefault((int(owner[p]), int(level[p])), set()).add((int(owner[f]), int(level[f])))
+    end = np.zeros((nparts, nlev))
+    for L in range(nlev):
+        for r in range(nparts):
+            start = end[r, L - 1] if L > 0 else 0.0
+            for (rs, Ls) in need.get((r, L), ()):
+                start = max(start, end[rs, Ls])
+            end[r, L] = start + cost[r, L]
+    crit = float(end.max())
+    return dict(top_flops_share=float(w[spans].sum() / total), speedup_bound=total / crit if crit > 0 else 1.0,
+                loads=[float(x) / total for x in cost.sum(axis=1)])
 
 
 def _c_size(sym, f):
@@ -132,81 +155,203 @@ def _r_size(sym, f):
     return rk * (rk + 1) // 2 + rk * (int(sym.Rp[f + 1] - sym.Rp[f]) - rk)
 
 
-def factorize_distributed(sym, A, factor_subset=None, gather_R=True, oversplit=4):
+class _Csc:
+    """A's arrays in the types the C ABI wants, made once per factorization."""
+
+    def __init__(self, A):
+        import scipy.sparse as sp
+        A = sp.csc_matrix(A)
+        A.sort_indices()
+        self.Ap = np.ascontiguousarray(A.indptr, dtype=np.int64)
+        self.Ai = np.ascontiguousarray(A.indices, dtype=np.int64)
+        self.Ax = np.ascontiguousarray(A.data, dtype=np.float64)
+
+
+def _bind_subset(L):
+    if getattr(L, "_subset_bound", False):
+        return
+    L.spqrgpu_amd_factorize_subset.restype = C.c_int
+    L.spqrgpu_amd_factorize_subset.argtypes = [C.c_void_p] * 6 + [C.POINTER(C.POINTER(spqr.Numeric))]
+    L.spqrgpu_amd_factorize_subset_dev.restype = C.c_int
+    L.spqrgpu_amd_factorize_subset_dev.argtypes = [C.c_void_p] * 7 + [C.POINTER(C.POINTER(spqr.Numeric))]
+    L.spqrgpu_amd_subset_csize.restype = C.c_int64
+    L.spqrgpu_amd_subset_csize.argtypes = [C.c_void_p, C.c_void_p]
+    L._subset_bound = True
+
+
+def _collect(sym, num, mine_c, want_R):
+    """R blocks (copies) and the offsets of the leaving contribution blocks of a finished call."""
+    Rblocks, Coff = {}, {}
+    fnn = np.diff(sym.Rp)
+    fpp = np.diff(sym.Super)
+    for f in np.nonzero(mine_c)[0]:
+        f = int(f)
+        if want_R:
+            rk = min(int(sym.Fm[f]), int(fpp[f]))
+            size = rk * (rk + 1) // 2 + rk * (int(fnn[f]) - rk)
+            off = num.Rblock[f]
+            Rblocks[f] = np.ctypeslib.as_array(num.Rstack, shape=(max(num.rsize, 1),))[off:off + size].copy()
+        if num.Cblock[f] >= 0:
+            Coff[f] = int(num.Cblock[f])
+    stats = dict(kernel_ms=float(num.gpuKernelTime), flops=int(num.gpuFlops), launches=int(num.gpuNumKernelLaunches),
+                 groups=int(num.numStagesRun))
+    return Rblocks, Coff, stats
+
+
+def gpu_factor_subset(sym, A, mine, limbo, want_R=True):
+    """spqrgpu_amd_factorize_subset on the current HIP device, contribution blocks in host memory on
+    both sides.  Returns (Rblocks, Cblocks, stats): dicts front -> packed R block / compact C block."""
+    L = spqr._bind()
+    _bind_subset(L)
+    csc = A if isinstance(A, _Csc) else _Csc(A)
+    nf = sym.nf
+    mine_c = np.ascontiguousarray(mine, dtype=np.int8)
+    ptrs = (C.c_void_p * max(nf, 1))()
+    keep = []
+    for c, blk in limbo.items():
+        b = np.ascontiguousarray(blk, dtype=np.float64)
+        keep.append(b)
+        ptrs[c] = b.ctypes.data
+    out = C.POINTER(spqr.Numeric)()
+    code = L.spqrgpu_amd_factorize_subset(sym._h, csc.Ap.ctypes.data, csc.Ai.ctypes.data, csc.Ax.ctypes.data,
+                                          mine_c.ctypes.data, C.cast(ptrs, C.c_void_p), C.byref(out))
+    if code != 0:
+        raise RuntimeError("spqrgpu_amd_factorize_subset failed with code %d" % code)
+    num = out.contents
+    Rblocks, Coff, stats = _collect(sym, num, mine_c, want_R)
+    Cblocks = {}
+    for f, coff in Coff.items():
+        csz = _c_size(sym, f)
+        Cblocks[f] = np.ctypeslib.as_array(num.Cstack, shape=(max(coff + csz, 1),))[coff:coff + csz].copy()
+    L.spqr_amd_numeric_free(out)
+    return Rblocks, Cblocks, stats
+
+
+def gpu_factor_subset_dev(sym, A, mine, limbo, want_R=True):
+    """spqrgpu_amd_factorize_subset_dev: the incoming blocks (`limbo`: front -> torch tensor on the
+    current device) are assembled from where they lie, the leaving ones are written into one new device
+    tensor.  Returns (Rblocks, Cblocks, stats) with Cblocks: front -> view into that tensor."""
+    import torch
+    L = spqr._bind()
+    _bind_subset(L)
+    csc = A if isinstance(A, _Csc) else _Csc(A)
+    nf = sym.nf
+    mine_c = np.ascontiguousarray(mine, dtype=np.int8)
+    ptrs = (C.c_void_p * max(nf, 1))()
+    for c, t in limbo.items():
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() == _c_size(sym, c)
+        ptrs[c] = t.data_ptr() if t.numel() > 0 else None
+    csize = int(L.spqrgpu_amd_subset_csize(sym._h, mine_c.ctypes.data))
+    cout = torch.empty(max(csize, 1), dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+    torch.cuda.synchronize()            # the incoming blocks were written on torch's streams
+    out = C.POINTER(spqr.Numeric)()
+    code = L.spqrgpu_amd_factorize_subset_dev(sym._h, csc.Ap.ctypes.data, csc.Ai.ctypes.data, csc.Ax.ctypes.data,
+                                              mine_c.ctypes.data, C.cast(ptrs, C.c_void_p), cout.data_ptr(), C.byref(out))
+    if code != 0:
+        raise RuntimeError("spqrgpu_amd_factorize_subset_dev failed with code %d" % code)
+    num = out.contents
+    Rblocks, Coff, stats = _collect(sym, num, mine_c, want_R)
+    Cblocks = {f: cout[coff:coff + _c_size(sym, f)] for f, coff in Coff.items()}
+    L.spqr_amd_numeric_free(out)
+    return Rblocks, Cblocks, stats
+
+
+def factorize_distributed(sym, A, factor_subset=None, gather_R=True):
     """Factorize A = QR over the ranks of the default torch.distributed group.
 
-    Every rank calls this with the same `sym` and `A`.  Phase 1: each rank factorizes its
-    subtrees.  Exchange: the subtree roots' contribution blocks go to rank 0, one message per
-    rank.  Phase 2: rank 0 factorizes the top fronts.  With gather_R, rank 0 also collects every
-    R block and returns R (scipy CSC); other ranks return None for it.
-    Returns (R or None, info dict).
+    Every rank calls this with the same `sym` and `A`.  For L = 0, 1, ...: each rank factorizes its
+    fronts of level L (one call of the subset driver), then the contribution blocks that leave those
+    calls travel to the rank that owns the parent, all of a level's transfers in one batch of
+    point-to-point sends and receives.  With the nccl backend the blocks go device to device; with
+    gloo they are staged through host tensors.  `factor_subset` (sym, A, mine, limbo) -> (R, C, stats)
+    replaces the GPU driver by a host one working on numpy blocks (the CPU tests pass the oracle).
+    With gather_R, rank 0 also collects every R block and returns R (scipy CSC); other ranks return
+    None for it.  Returns (R or None, info dict).
     """
     import torch
     import torch.distributed as dist
 
-    if factor_subset is None:
-        factor_subset = gpu_factor_subset
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(), dist.get_world_size()
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        nccl = dist.get_backend() == "nccl"
     else:
-        rank, world, dev = 0, 1, torch.device("cpu")
+        rank, world, nccl = 0, 1, False
+    host_blocks = factor_subset is not None      # numpy blocks, host driver
+    cdev = torch.device("cuda", torch.cuda.current_device()) if (nccl or not host_blocks) else torch.device("cpu")
+    wire = cdev if nccl else torch.device("cpu")        # where a tensor must live to be sent
+
     nf = sym.nf
-    owner, top = partition_subtrees(sym, world, oversplit)
+    owner, level = map_tree(sym, world)
     Parent = sym.Parent
-    # fronts whose contribution block crosses the cut: parent is a top front, front itself is not
-    cut = [f for f in range(nf) if not top[f] and Parent[f] < nf and top[Parent[f]]]
+    csc = A if (host_blocks or isinstance(A, _Csc)) else _Csc(A)
+    nlev = int(level.max()) + 1 if nf > 0 else 0
+    # fronts whose block leaves the call that makes it, by level
+    leaving = [[] for _ in range(nlev)]
+    for f in range(nf):
+        p = Parent[f]
+        if p < nf and (owner[p] != owner[f] or level[p] != level[f]):
+            leaving[level[f]].append(f)
+    info = dict(rank=rank, world=world, levels=nlev, calls=[],
+                n_cut=sum(1 for L in leaving for f in L if owner[Parent[f]] != owner[f]),
+                cut_bytes=8 * sum(_c_size(sym, f) for L in leaving for f in L if owner[Parent[f]] != owner[f]))
+    info.update(mapping_report(sym, owner, level, world))
 
-    mine1 = (owner == rank) & ~top
-    R1, C1, st1 = factor_subset(sym, A, mine1, {})
-    info = dict(rank=rank, world=world, phase1=st1, n_top=int(top.sum()), n_cut=len(cut),
-                cut_bytes=8 * sum(_c_size(sym, f) for f in cut))
-
-    # ---- contribution blocks of the cut to rank 0: one flat message per sending rank -------------
-    limbo = {}
-    if rank == 0:
-        for f in cut:
-            if owner[f] == 0:
-                limbo[f] = C1[f]
-        for src in range(1, world):
-            fs = [f for f in cut if owner[f] == src]
-            total = sum(_c_size(sym, f) for f in fs)
-            if total == 0:
-                continue
-            buf = torch.empty(total, dtype=torch.float64, device=dev)
-            dist.recv(buf, src=src)
-            flat = buf.cpu().numpy()
-            off = 0
-            for f in fs:
-                sz = _c_size(sym, f)
-                limbo[f] = flat[off:off + sz]
-                off += sz
-    else:
-        fs = [f for f in cut if owner[f] == rank]
-        total = sum(_c_size(sym, f) for f in fs)
-        if total > 0:
-            flat = np.concatenate([np.asarray(C1[f]).ravel() for f in fs]) if fs else np.zeros(0)
-            dist.send(torch.from_numpy(flat).to(dev), dst=0)
-
-    R2 = {}
-    if rank == 0 and top.any():
-        R2, C2, st2 = factor_subset(sym, A, top, limbo)
-        info["phase2"] = st2
+    held = {}           # front -> its contribution block, waiting here for the parent's call
+    Rall = {}
+    for L in range(nlev):
+        mine = (owner == rank) & (level == L)
+        Cout = {}
+        if mine.any():
+            limbo = {}
+            for f in np.nonzero(mine)[0]:
+                for c in _children(sym, int(f)):
+                    if not mine[c]:
+                        limbo[c] = held[c]
+            if host_blocks:
+                R, Cout, st = factor_subset(sym, csc, mine, limbo)
+            else:
+                R, Cout, st = gpu_factor_subset_dev(sym, csc, mine, limbo, want_R=gather_R)
+            for c in limbo:
+                del held[c]
+            if gather_R:
+                Rall.update(R)
+            info["calls"].append(dict(level=L, fronts=int(mine.sum()), **st))
+        # ---- the blocks that left level L, to whoever factorizes the parent ------------------------
+        ops, landing = [], []
+        for f in leaving[L]:                            # increasing f on every rank: the pairs match up
+            src, dst = int(owner[f]), int(owner[Parent[f]])
+            if src == rank and dst == rank:
+                held[f] = Cout[f]
+            elif src == rank:
+                blk = Cout[f]
+                t = torch.from_numpy(np.ascontiguousarray(blk)) if host_blocks else blk
+                if t.numel() > 0:
+                    ops.append(dist.P2POp(dist.isend, t.to(wire), dst))
+            elif dst == rank:
+                t = torch.empty(_c_size(sym, f), dtype=torch.float64, device=wire)
+                landing.append((f, t))
+                if t.numel() > 0:
+                    ops.append(dist.P2POp(dist.irecv, t, src))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            if wire.type == "cuda":
+                torch.cuda.synchronize()
+        for f, t in landing:
+            held[f] = t.numpy() if host_blocks else t.to(cdev)
 
     if not gather_R:
         return None, info
 
-    # ---- R blocks to rank 0 ---------------------------------------------------------------------
-    Rall = dict(R1)
-    Rall.update(R2)
+    # ---- R blocks to rank 0 (host memory; not part of the timed path) -------------------------------
     if world > 1:
         if rank == 0:
             for src in range(1, world):
-                fs = [f for f in range(nf) if owner[f] == src and not top[f]]
+                fs = [f for f in range(nf) if owner[f] == src]
                 total = sum(_r_size(sym, f) for f in fs)
                 if total == 0:
                     continue
-                buf = torch.empty(total, dtype=torch.float64, device=dev)
+                buf = torch.empty(total, dtype=torch.float64, device=wire)
                 dist.recv(buf, src=src)
                 flat = buf.cpu().numpy()
                 off = 0
@@ -215,11 +360,11 @@ def factorize_distributed(sym, A, factor_subset=None, gather_R=True, oversplit=4
                     Rall[f] = flat[off:off + sz]
                     off += sz
         else:
-            fs = [f for f in range(nf) if owner[f] == rank and not top[f]]
+            fs = [f for f in range(nf) if owner[f] == rank]
             total = sum(_r_size(sym, f) for f in fs)
             if total > 0:
-                flat = np.concatenate([np.asarray(R1[f]).ravel() for f in fs])
-                dist.send(torch.from_numpy(flat).to(dev), dst=0)
+                flat = np.concatenate([np.asarray(Rall[f]).ravel() for f in fs])
+                dist.send(torch.from_numpy(flat).to(wire), dst=0)
             return None, info
     return blocks_to_csc(sym, Rall), info
 

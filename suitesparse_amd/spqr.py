@@ -26,7 +26,7 @@ class Numeric(C.Structure):
                 ("gpuFlops", C.c_int64), ("gpuNumKernelLaunches", C.c_int64),
                 ("numStagesRun", C.c_int64), ("assembleBytes", C.c_double),
                 ("Cstack", C.POINTER(C.c_double)), ("Cblock", C.POINTER(C.c_int64)),
-                ("RstackPinned", C.c_int64)]
+                ("RstackPinned", C.c_int64), ("csize", C.c_int64)]
 
 
 _ARRAYS = ["Qfill", "PLinv", "Sleft", "Sp", "Sj", "Super", "Rp", "Rj", "Parent", "Childp", "Child",
@@ -105,9 +105,12 @@ def factorize(sym, A, want_R=True):
     """spqrgpu_amd_factorize (+ spqr_amd_rconvert when want_R): returns R (scipy CSC,
     sumfrank-by-n) and stats."""
     L = _bind()
-    A = sp.csc_matrix(A)
-    A.sort_indices()
-    Ap, Ai, Ax = _i64(A.indptr), _i64(A.indices), np.ascontiguousarray(A.data, dtype=np.float64)
+    if hasattr(A, "Ap"):                # arrays already in the C ABI's types (multigpu._Csc)
+        Ap, Ai, Ax = A.Ap, A.Ai, A.Ax
+    else:
+        A = sp.csc_matrix(A)
+        A.sort_indices()
+        Ap, Ai, Ax = _i64(A.indptr), _i64(A.indices), np.ascontiguousarray(A.data, dtype=np.float64)
     out = C.POINTER(Numeric)()
     code = L.spqrgpu_amd_factorize(sym._h, _p(Ap), _p(Ai), _p(Ax), C.byref(out))
     if code != 0:

@@ -74,7 +74,7 @@ def main():
     R, info = multigpu.factorize_distributed(sym, A, factor_subset=fs)
     if rank == 0:
         np.savez(out_path, data=R.data, indices=R.indices, indptr=R.indptr, shape=np.array(R.shape),
-                 n_cut=info["n_cut"], n_top=info["n_top"], Qfill=sym.Qfill)
+                 n_cut=info["n_cut"], levels=info["levels"], bound=info["speedup_bound"], Qfill=sym.Qfill)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -14,31 +14,45 @@ from tests.util import r_rel_diff, rownorm_sign
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_partition_covers_tree_and_balances():
-    A = problems.stacked_ls((24, 24))
-    sym = spqr.analyze(A, problems.nested_dissection((24, 24), leaf=3), gpuMemorySize=2**34)
-    for parts in (1, 2, 4, 8):
-        owner, top = multigpu.partition_subtrees(sym, parts)
+@pytest.mark.parametrize("shape,leaf", [((24, 24), 3), ((12, 12, 12), 3)])
+def test_mapping_covers_tree_and_never_loses_to_one_rank(shape, leaf):
+    A = problems.stacked_ls(shape)
+    sym = spqr.analyze(A, problems.nested_dissection(shape, leaf=leaf), gpuMemorySize=2**34)
+    nf = sym.nf
+    w = multigpu.front_weights(sym)
+    for parts in (1, 2, 3, 4, 8):
+        owner, level = multigpu.map_tree(sym, parts)
         assert owner.min() >= 0 and owner.max() < parts
-        # a front that is not top has the same owner as all its descendants
-        for f in range(sym.nf):
+        for f in range(nf):
             p = sym.Parent[f]
-            if p < sym.nf and not top[p]:
-                assert owner[f] == owner[p] and not top[f]
-        # top fronts form an ancestor-closed set on rank 0
-        for f in range(sym.nf):
-            if top[f]:
-                assert owner[f] == 0
-                assert sym.Parent[f] == sym.nf or top[sym.Parent[f]]
-        if parts > 1:
-            # below the cut the ranks are balanced; the top set stays on rank 0 by design
-            w = multigpu.front_weights(sym)
+            if p < nf:
+                # a call takes blocks only from calls of lower levels, or from itself
+                assert level[p] >= level[f] + (1 if owner[p] != owner[f] else 0)
+        rep = multigpu.mapping_report(sym, owner, level, parts)
+        assert abs(sum(rep["loads"]) - 1.0) < 1e-9
+        assert rep["speedup_bound"] >= 1.0 - 1e-12           # splitting never does worse than one rank
+        assert rep["speedup_bound"] <= parts + 1e-9
+        if parts == 1:
+            assert rep["top_flops_share"] == 0.0 and level.max() == 0
+        else:
             load = np.array([w[owner == r].sum() for r in range(parts)])
-            assert load.min() > 0
-            assert load.max() <= max(1.5 * load.mean(), 1.01 * w[top].sum())
+            assert load.min() > 0                            # nobody idles on a balanced grid
+            assert rep["speedup_bound"] > 1.15               # and the split pays
+            # the root's rank carries the chain of separators above its subtree, no more
+            assert load.max() <= rep["top_flops_share"] * w.sum() + 1.5 * w.sum() / parts
 
 
-@pytest.mark.parametrize("world,shape", [(2, "14x14"), (3, "7x7x7")])
+def test_mapping_of_a_chain_stays_on_one_rank():
+    """A tree with nothing to run side by side: everything lands on one rank and the bound says 1."""
+    n = 40
+    A = sp.diags([np.ones(n), np.ones(n - 1)], [0, 1], shape=(n, n), format="csc") + sp.eye(n, format="csc")
+    sym = spqr.analyze(sp.vstack([A, sp.eye(n)]).tocsc(), None, gpuMemorySize=2**30)
+    owner, level = multigpu.map_tree(sym, 4)
+    rep = multigpu.mapping_report(sym, owner, level, 4)
+    assert abs(rep["speedup_bound"] - 1.0) < 0.35
+
+
+@pytest.mark.parametrize("world,shape", [(2, "14x14"), (3, "7x7x7"), (4, "9x9x9")])
 def test_distributed_factorization_gloo(tmp_path, world, shape):
     out = str(tmp_path / "R.npz")
     port = 29500 + (os.getpid() % 2000)
@@ -50,7 +64,7 @@ def test_distributed_factorization_gloo(tmp_path, world, shape):
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     z = np.load(out)
     R = sp.csc_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"])).toarray()
-    assert int(z["n_cut"]) >= world and int(z["n_top"]) >= 1
+    assert int(z["n_cut"]) >= world - 1 and int(z["levels"]) >= 2
     dims = tuple(int(x) for x in shape.split("x"))
     A = problems.stacked_ls(dims)
     Rl = np.linalg.qr(A[:, z["Qfill"]].toarray(), mode="r")

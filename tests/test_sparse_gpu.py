@@ -99,34 +99,80 @@ def test_rank_deficient_hits_the_wall():
     assert res.Rdead.sum() == 4 - res.rank
 
 
-def test_subtree_parallel_two_ranks_on_one_gpu(tmp_path):
-    """Two processes (gloo exchange) sharing the test box's one GPU: each factorizes its subtrees
-    with spqrgpu_amd_factorize_subset, rank 0 receives the contribution blocks and finishes the top."""
+@pytest.mark.parametrize("world,shape", [(2, "20x20"), (2, "10x10x10"), (3, "9x9x9")])
+def test_tree_mapped_ranks_on_one_gpu(tmp_path, world, shape):
+    """Several processes (gloo exchange) sharing the test box's one GPU: the tree is mapped onto the
+    ranks, each factorizes its fronts level by level with spqrgpu_amd_factorize_subset_dev (contribution
+    blocks stay on the device on both sides of a call), the blocks that change rank travel point to
+    point.  R against LAPACK."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "R.npz")
     port = 29500 + (os.getpid() % 2000)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "tests", "mgpu_worker.py"), "gloo-gpu", out, "20x20"]
+           os.path.join(root, "tests", "mgpu_worker.py"), "gloo-gpu", out, shape]
     # own process group, so that a hang can be ended together with the workers it left behind
     import signal
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
-        stdout, stderr = proc.communicate(timeout=90)
+        stdout, stderr = proc.communicate(timeout=120)
     except subprocess.TimeoutExpired:
         os.killpg(proc.pid, signal.SIGKILL)
         stdout, stderr = proc.communicate()
-        raise AssertionError("two-rank run hung:\n" + stdout[-3000:] + stderr[-3000:])
+        raise AssertionError("multi-rank run hung:\n" + stdout[-3000:] + stderr[-3000:])
     assert proc.returncode == 0, stdout[-2000:] + stderr[-2000:]
     z = np.load(out)
     R = sp.csc_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"])).toarray()
-    A = problems.stacked_ls((20, 20))
+    dims = tuple(int(x) for x in shape.split("x"))
+    A = problems.stacked_ls(dims)
     Rl = np.linalg.qr(A[:, z["Qfill"]].toarray(), mode="r")
-    assert int(z["n_cut"]) >= 2
+    assert int(z["n_cut"]) >= world - 1 and int(z["levels"]) >= 2
     assert r_rel_diff(rownorm_sign(R), rownorm_sign(Rl)) <= 1e-12
+
+
+@pytest.mark.parametrize("mem", [0, 14_000_000, 2**34])
+@pytest.mark.parametrize("dev_blocks", [False, True])
+def test_subset_driver_in_groups_and_pieces(mem, dev_blocks):
+    """The subset driver on one process: the tree cut into three pieces (two subtrees, then the rest)
+    that are factorized by three calls, blocks handed from call to call on the host or on the device;
+    with little declared memory every call runs in several groups.  Same R as the whole-tree driver."""
+    import torch
+    from suitesparse_amd import multigpu
+    shape = (9, 9, 9)
+    A = problems.stacked_ls(shape)
+    Q = problems.nested_dissection(shape, leaf=2)
+    one = spqr.factorize(spqr.analyze(A, Q, gpuMemorySize=2**34), A)
+    sym = spqr.analyze(A, Q, gpuMemorySize=mem)
+    nf = sym.nf
+    owner, level = multigpu.map_tree(sym, 3)
+    pieces = [(owner == r) & (level == L) for L in range(int(level.max()) + 1) for r in range(3)]
+    pieces = [p for p in pieces if p.any()]
+    assert len(pieces) >= 3
+    held, Rall, groups = {}, {}, 0
+    for mine in pieces:
+        limbo = {c: held[c] for f in np.nonzero(mine)[0] for c in multigpu._children(sym, int(f)) if not mine[c]}
+        if dev_blocks:
+            Rb, Cb, st = multigpu.gpu_factor_subset_dev(sym, A, mine, limbo)
+            Cb = {f: t.clone() for f, t in Cb.items()}
+        else:
+            Rb, Cb, st = multigpu.gpu_factor_subset(sym, A, mine, limbo)
+        groups += st["groups"]
+        held.update(Cb)
+        Rall.update(Rb)
+    torch.cuda.synchronize()
+    assert len(Rall) == nf
+    if mem == 0:
+        assert groups == nf                      # every front a group of its own
+    elif mem < 2**30:
+        assert len(pieces) < groups < nf         # the declared memory forced several groups per call
+    else:
+        assert groups == len(pieces)
+    R = multigpu.blocks_to_csc(sym, Rall)
+    assert R.shape == one.R.shape and R.nnz == one.R.nnz
+    assert np.abs((R - one.R)).max() <= 1e-13 * np.abs(one.R).max()
 
 
 @pytest.mark.parametrize("grid,leaf", [((24, 24), 4), ((8, 8, 8), 2)])
