@@ -4,6 +4,7 @@ and per-kernel HBM traffic from two --pmc passes (FETCH_SIZE, WRITE_SIZE) as JSO
   python scripts/rocpd_summary.py stats  kt_results.db  out.csv
   python scripts/rocpd_summary.py pmc    f_results.db w_results.db  out.json out.md
   python scripts/rocpd_summary.py gaps   kt_results.db
+  python scripts/rocpd_summary.py counters  pmc_results.db  out.md      (every counter of the pass, per kernel)
 """
 import csv
 import json
@@ -40,7 +41,30 @@ def per_kernel(db_path, counter):
     return out
 
 
-def pmc(fetch_db, write_db, out_json, out_md):
+def counters(db_path, out_md):
+    """Sum of every counter of a --pmc pass per kernel, and the ratios that say how busy the matrix pipe was."""
+    db = sqlite3.connect(db_path)
+    agg, cnt = {}, {}
+    for name, counter, n, tot in db.execute("select name, counter_name, count(*), sum(counter_value) from pmc_events "
+                                            "group by name, counter_name"):
+        k = short(name)
+        if not k.startswith("k_"):
+            continue
+        agg.setdefault(k, {})[counter] = tot
+        cnt[k] = n
+    names = sorted({c for v in agg.values() for c in v})
+    with open(out_md, "w") as f:
+        f.write("| kernel | launches | " + " | ".join(names) + " | MFMA busy / SQ busy |\n")
+        f.write("|---|---|" + "---|" * (len(names) + 1) + "\n")
+        for k in sorted(agg, key=lambda k: -agg[k].get("SQ_BUSY_CYCLES", 0)):
+            v = agg[k]
+            ratio = ""
+            if v.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+                ratio = "%.3f" % (v["SQ_VALU_MFMA_BUSY_CYCLES"] / v["SQ_BUSY_CYCLES"])
+            f.write("| %s | %d | " % (k, cnt[k]) + " | ".join("%.4g" % v.get(c, 0) for c in names) + " | %s |\n" % ratio)
+
+
+def pmc(fetch_db, write_db, out_json, out_md, tag="dense", command=None):
     fe, wr = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
     kernels = {}
     for k in sorted(fe, key=lambda k: -fe[k][1]):
@@ -51,7 +75,8 @@ def pmc(fetch_db, write_db, out_json, out_md):
         write = 1024.0 * wr[k][1] / n
         kernels[k] = {"dispatches": n, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
                       "traffic_bytes_per_launch": fetch + write}
-    json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py "
+    json.dump({"workload_tag": tag,
+               "command": command or "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py "
                           "--no-cpu-baseline --steps 1 --warmup 0",
                "corrections": "counter unit KB; FETCH_SIZE doubled on gfx950 (128-B requests counted as 64 B); "
                               "WRITE_SIZE as is",
@@ -107,5 +132,7 @@ if __name__ == "__main__":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "gaps":
         gaps(sys.argv[2])
+    elif sys.argv[1] == "counters":
+        counters(sys.argv[2], sys.argv[3])
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
+        pmc(*sys.argv[2:])

@@ -711,7 +711,7 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
     hvec<int64_t> evProfBucket ;      // per profiled launch: first bucket, workgroups, kernel id
     hvec<int64_t> evProfN ;
     hvec<int> evProfKid ;
-    int64_t launches = 0 ;
+    int64_t launches = 0, synced_at = 0 ;
     float ms = 0 ;
     try
     {
@@ -913,6 +913,16 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
                         if (nrows > fr.fm) nrows = fr.fm ;
                         HIP_TRY (pull_rows (fr, nrows, sCopy)) ;
                     }
+                }
+                // GPUQR_SYNC_EVERY=n: wait for the device every n launches.  Off by default; a profiler
+                // that keeps a record per launch in flight was seen to crash with 40,000 launches queued.
+                static int sync_every = -1 ;
+                if (sync_every < 0) { const char *e = getenv ("GPUQR_SYNC_EVERY") ; sync_every = e ? atoi (e) : 0 ; }
+                if (sync_every > 0 && launches - synced_at >= sync_every)
+                {
+                    HIP_TRY (hipStreamSynchronize (sCompute)) ;
+                    HIP_TRY (hipStreamSynchronize (sApply)) ;
+                    synced_at = launches ;
                 }
                 // R blocks of the fronts that became final in this group of rounds
                 if (((r + 1) % rgroup == 0 || r == nrounds - 1) && rout.due (r / rgroup))
