@@ -1,0 +1,92 @@
+// Drop-in translation unit for an SPQR build: the reference's entry point
+//
+//     void spqrgpu_kernel (spqr_blob <double> *Blob) ;                (SPQR/Include/spqrgpu.hpp:9-14)
+//
+// implemented on libgpuqrengine_amd.so.  It replaces SPQR/SPQRGPU/spqrgpu_kernel.cpp in the list of
+// SPQR's sources; spqr_kernel (SPQR/Source/spqr_kernel.cpp:35-42) calls it unchanged.  It is written
+// against SPQR's own headers and is compiled inside an SPQR tree, not in this repository (which
+// holds none of SPQR's headers); the work is done by spqrgpu_amd_kernel (include/spqrgpu_amd.h),
+// which this repository tests on the same arrays.
+//
+// Build: add -DSUITESPARSE_HIP (this file's own gate; SPQR's -DSUITESPARSE_CUDA pulls CUDA headers
+// into cholmod_core.h) and -I<this repo>/include, link -lgpuqrengine_amd.
+//
+// What it reads and writes is what the reference's function reads and writes
+// (SPQR/SPQRGPU/spqrgpu_kernel.cpp:63-782): QRsym's arrays and QRsym->QRgpu, Blob->Sx,
+// cc->gpuMemorySize in; QRnum->Rblock[], QRnum->Rdead[], Work[0].Stack_head / sumfrank / maxfrank,
+// cc->gpuKernelTime / gpuFlops / gpuNumKernelLaunches and cc->status out.
+
+#ifdef SUITESPARSE_HIP
+
+#include "spqr.hpp"
+#include "spqrgpu_amd.h"
+
+void spqrgpu_kernel (spqr_blob <double> *Blob)
+{
+    spqr_symbolic *QRsym = Blob->QRsym ;
+    spqr_numeric <double> *QRnum = Blob->QRnum ;
+    spqr_work <double> *Work = Blob->Work ;
+    cholmod_common *cc = Blob->cc ;
+    spqr_gpu *QRgpu = QRsym->QRgpu ;
+    const Long nf = QRsym->nf ;
+    const Long stack = 0 ;                      // no mixing of GPU and TBB parallelism
+
+    // The symbolic object of the AMD driver: a copy of the arrays above.  A caller that factorizes
+    // many matrices on one QRsym keeps it (for instance in a slot beside QRsym->QRgpu): the driver
+    // then reuses the assembly maps, the S permutation and the engine's schedule between calls.
+    int status = 0 ;
+    spqr_amd_symbolic *sym = spqr_amd_symbolic_from_arrays (QRsym->m, QRsym->n, QRsym->anz, nf,
+        QRsym->Sp, QRsym->Sj, QRsym->Sleft, QRsym->Super, QRsym->Rp, QRsym->Rj,
+        QRsym->Parent, QRsym->Childp, QRsym->Child, QRsym->Post, QRsym->Fm, QRsym->Cm,
+        QRgpu->RimapOffsets, QRgpu->RimapSize, QRgpu->RjmapOffsets, QRgpu->RjmapSize,
+        QRgpu->numStages, QRgpu->Stagingp, QRgpu->StageMap, cc->gpuMemorySize, &status) ;
+    if (!sym)
+    {
+        ERROR (status == 1 ? CHOLMOD_OUT_OF_MEMORY : CHOLMOD_INVALID, "cannot set up the GPU factorization") ;
+        return ;
+    }
+
+    double *Stack_head = Work [stack].Stack_head ;
+    double *Stack_top = Work [stack].Stack_top ;
+    Long *Rblock_offset = (Long *) cholmod_l_malloc (MAX (nf, 1), sizeof (Long), cc) ;
+    if (cc->status < CHOLMOD_OK)
+    {
+        spqr_amd_symbolic_free (sym) ;
+        return ;
+    }
+
+    Long sumfrank = 0, maxfrank = 0, used = 0, flops = 0, launches = 0 ;
+    double kernel_ms = 0 ;
+    int code = spqrgpu_amd_kernel (sym, Blob->Sx, Stack_head, (Long) (Stack_top - Stack_head),
+        Rblock_offset, QRnum->Rdead, &sumfrank, &maxfrank, &used, &kernel_ms, &flops, &launches) ;
+    if (code == 0)
+    {
+        for (Long f = 0 ; f < nf ; f++) QRnum->Rblock [f] = Stack_head + Rblock_offset [f] ;
+        Work [stack].Stack_head = Stack_head + used ;
+        Work [stack].Stack_top = Stack_top ;
+        Work [stack].sumfrank += sumfrank ;
+        Work [stack].maxfrank = MAX (Work [stack].maxfrank, maxfrank) ;
+        cc->gpuKernelTime = kernel_ms ;
+        cc->gpuFlops = flops ;
+        cc->gpuNumKernelLaunches = launches ;
+    }
+    cholmod_l_free (MAX (nf, 1), sizeof (Long), Rblock_offset, cc) ;
+    spqr_amd_symbolic_free (sym) ;
+    // (the reference ignores the engine's return code, spqrgpu_kernel.cpp:638; here a failure reaches cc)
+    if (code == 1) ERROR (CHOLMOD_OUT_OF_MEMORY, "out of memory") ;
+    else if (code != 0) ERROR (CHOLMOD_GPU_PROBLEM, "GPU factorization failed") ;
+}
+
+void spqrgpu_kernel (spqr_blob <Complex> *Blob)
+{
+    // complex case not supported on the GPU, as in the reference (spqrgpu_kernel.cpp:786-795)
+    cholmod_common *cc = Blob->cc ;
+    ERROR (CHOLMOD_INVALID, "complex case not yet supported on the GPU") ;
+}
+
+// void spqrgpu_computeFrontStaging (...) (SPQR/Include/spqrgpu.hpp:16-57) and
+// void spqrgpu_buildAssemblyMaps (...) (spqrgpu.hpp:59-82) bind to
+// spqrgpu_amd_compute_front_staging / spqrgpu_amd_build_assembly_maps the same way; the two wrappers
+// are shown in INTEGRATION.md.
+
+#endif

@@ -74,6 +74,28 @@ spqr_amd_symbolic *spqr_amd_analyze
 
 void spqr_amd_symbolic_free (spqr_amd_symbolic *sym);
 
+/* The symbolic object of an SPQR build: the arrays spqrgpu_kernel reads out of QRsym and
+ * QRsym->QRgpu (SPQR/SPQRGPU/spqrgpu_kernel.cpp:85-143, SPQR/Include/SuiteSparseQR.hpp:21-38,60-196),
+ * copied.  m, n, anz: S = A(P,Q) is m-by-n with anz entries; Sp (m+1), Sj (anz, front-local column
+ * indices as spqr_analyze leaves them for the GPU path, SPQR/Source/spqr_analyze.cpp:858-882),
+ * Sleft (n+2), Super (nf+1), Rp (nf+1), Rj (Rp[nf]), Parent (nf+1), Childp (nf+2), Child (nf+1),
+ * Post (nf), Fm (nf), Cm (nf), RimapOffsets / RjmapOffsets (nf) with their sizes, the staging
+ * (numStages, Stagingp (numStages+1), StageMap (nf)) and cc->gpuMemorySize.  An object made this way
+ * is factorized with spqrgpu_amd_kernel (values as Sx); it has no Qfill / PLinv, so the entry
+ * points that take A's compressed columns refuse it.  *status: 0 ok, 1 out of memory, 3 invalid
+ * input. */
+spqr_amd_symbolic *spqr_amd_symbolic_from_arrays
+(
+    int64_t m, int64_t n, int64_t anz, int64_t nf,
+    const int64_t *Sp, const int64_t *Sj, const int64_t *Sleft,
+    const int64_t *Super, const int64_t *Rp, const int64_t *Rj,
+    const int64_t *Parent, const int64_t *Childp, const int64_t *Child, const int64_t *Post,
+    const int64_t *Fm, const int64_t *Cm,
+    const int64_t *RimapOffsets, int64_t RimapSize, const int64_t *RjmapOffsets, int64_t RjmapSize,
+    int64_t numStages, const int64_t *Stagingp, const int64_t *StageMap,
+    size_t gpuMemorySize, int *status
+);
+
 /* Named access: arrays "Qfill" "PLinv" "Sleft" "Sp" "Sj" "Super" "Rp" "Rj" "Parent" "Childp" "Child"
  * "Post" "Fm" "Cm" "RjmapOffsets" "RimapOffsets" "Stagingp" "StageMap" "FSize" "RSize" "SSize"
  * "FOffsets" "ROffsets" "SOffsets" "ColCount"; returns NULL for an unknown name. */
@@ -101,6 +123,7 @@ typedef struct spqr_amd_numeric
     int64_t *Cblock;        /* subset driver: size nf, offset of front f's block in Cstack or -1 */
     int64_t  RstackPinned;  /* 1: Rstack is pinned host memory; 0: the pinned allocation was refused and it is pageable */
     int64_t  csize;         /* subset driver: doubles of contribution blocks that left (in Cstack or the caller's device buffer) */
+    int64_t  RstackBorrowed;/* 1: Rstack is the caller's memory (spqrgpu_amd_kernel) and is not freed with the object */
 } spqr_amd_numeric;
 
 /* Replaces void spqrgpu_kernel (spqr_blob <double> *Blob)
@@ -112,6 +135,23 @@ int spqrgpu_amd_factorize (const spqr_amd_symbolic *sym, const int64_t *Ap, cons
                            const double *Ax, spqr_amd_numeric **num_out);
 
 void spqr_amd_numeric_free (spqr_amd_numeric *num);
+
+/* The body of void spqrgpu_kernel (spqr_blob <double> *Blob) on plain arrays
+ * (SPQR/Include/spqrgpu.hpp:9-14, SPQR/SPQRGPU/spqrgpu_kernel.cpp:63-782; adapter/spqrgpu_kernel.cpp
+ * is the translation unit with the reference's signature that calls it).  Sx = Blob->Sx, the values
+ * of S in row form.  The R blocks are written column-packed onto the caller's stack from Stack_head
+ * on (Work[0].Stack_head; stack_room doubles are available), front after front in postorder, stage
+ * after stage, as the reference lays them (spqrgpu_kernel.cpp:399-440); Rblock_offset[f] (size nf) is
+ * where front f's block starts relative to Stack_head, *stack_used how far the head moved.
+ * Rdead (size n) gets 1 for pivot columns past the bottom of their front (spqrgpu_kernel.cpp:753-771);
+ * sumfrank / maxfrank as Work[0]'s.  The three statistics feed cc->gpuKernelTime / gpuFlops /
+ * gpuNumKernelLaunches (spqrgpu_kernel.cpp:637-641).  Returns 0, 1 (out of memory: CHOLMOD_OUT_OF_MEMORY),
+ * 2 (CHOLMOD_GPU_PROBLEM) or 3 (invalid argument). */
+int spqrgpu_amd_kernel (const spqr_amd_symbolic *sym, const double *Sx,
+                        double *Stack_head, int64_t stack_room,
+                        int64_t *Rblock_offset, char *Rdead,
+                        int64_t *sumfrank, int64_t *maxfrank, int64_t *stack_used,
+                        double *gpuKernelTime, int64_t *gpuFlops, int64_t *gpuNumKernelLaunches);
 
 /* The numeric driver keeps its device workspaces (front arena, S, packed R) per device between
  * calls, grow-only, as the reference keeps its Workspace objects alive across stages

@@ -1634,6 +1634,14 @@ cleanup:
 // dense overload: host fronts in, R out
 // -----------------------------------------------------------------------------
 
+// Row pitch of the device copy of a dense front: even, so that with a 16-byte aligned base every
+// row starts on a 16-byte boundary (the update kernel moves two columns per lane); from 96 columns
+// on a multiple of 16 doubles, so that rows start on 128-byte lines.
+static inline int64_t dense_pitch (int64_t n)
+{
+    return (n >= 96) ? ((n + 15) & ~(int64_t) 15) : (n + (n & 1)) ;
+}
+
 extern "C" int gpuqr_factor_dense
 (
     size_t gpuMemorySize, gpuqr_front *userFronts, int64_t nf, gpuqr_stats *stats
@@ -1655,7 +1663,8 @@ extern "C" int gpuqr_factor_dense
     {
         gpuqr_front &u = userFronts [f] ;
         if (u.fm < 0 || u.fn < 0 || (u.fm > 0 && u.fn > 0 && (!u.F || !u.cpuR))) { code = GPUQR_GPUERROR ; goto cleanup ; }
-        FSize += (size_t) u.fm * (size_t) (u.fn + (u.fn & 1)) ;
+        FSize = (FSize + 15) & ~(size_t) 15 ;
+        FSize += (size_t) u.fm * (size_t) dense_pitch (u.fn) ;
         RSize += (size_t) std::min (u.fm, u.fn) * u.fn ;
     }
     // pinned staging copies: the H2D/D2H transfers then run asynchronously
@@ -1676,10 +1685,8 @@ extern "C" int gpuqr_factor_dense
             fr.fids = f ; fr.pids = -1 ; fr.fidg = u.fidg ; fr.pidg = u.pidg ;
             fr.fm = m ; fr.fn = n ; fr.fp = u.fp ; fr.rank = std::min (m, n) ;
             fr.is_sparse = 0 ;
-            // rows of the device copy are padded to an even length: with the 16-byte aligned
-            // base every row then starts on a 16-byte boundary, which the update kernel's
-            // two-column accesses want
-            const int64_t np = n + (n & 1) ;
+            const int64_t np = dense_pitch (n) ;
+            FOff = (FOff + 15) & ~(size_t) 15 ;
             fr.is_col_major = 0 ; fr.ldn = np ;
             double *F = hF + FOff ;
             fr.F = F ; fr.gpuF = dF + FOff ; fr.cpuR = hR + ROff ;
@@ -1687,7 +1694,7 @@ extern "C" int gpuqr_factor_dense
             {
                 for (int64_t j = 0 ; j < n ; j++)
                     F [i*np + j] = u.is_col_major ? u.F [j*ldn + i] : u.F [i*ldn + j] ;
-                if (np > n) F [i*np + n] = 0 ;
+                for (int64_t j = n ; j < np ; j++) F [i*np + j] = 0 ;
             }
             fr.Stair = u.Stair ;
             if (fr.Stair == NULL && m > 0 && n > 0)

@@ -397,6 +397,92 @@ extern "C" spqr_amd_symbolic *spqr_amd_analyze
     }
 }
 
+// The symbolic object from the arrays an SPQR build already has: what spqrgpu_kernel reads out of
+// QRsym and QRsym->QRgpu (SPQR/SPQRGPU/spqrgpu_kernel.cpp:85-143).  Everything is copied.  Sj must
+// hold front-local column indices, as spqr_analyze leaves it for the GPU path
+// (SPQR/Source/spqr_analyze.cpp:858-882).  The staging arrays are taken as given (numStages,
+// Stagingp, StageMap decide which fronts share a stage); the size and offset arrays of the
+// reference's arenas are not needed, this driver places the fronts of a stage itself.
+extern "C" spqr_amd_symbolic *spqr_amd_symbolic_from_arrays
+(
+    int64_t m, int64_t n, int64_t anz, int64_t nf,
+    const int64_t *Sp, const int64_t *Sj, const int64_t *Sleft,
+    const int64_t *Super, const int64_t *Rp, const int64_t *Rj,
+    const int64_t *Parent, const int64_t *Childp, const int64_t *Child, const int64_t *Post,
+    const int64_t *Fm, const int64_t *Cm,
+    const int64_t *RimapOffsets, int64_t RimapSize, const int64_t *RjmapOffsets, int64_t RjmapSize,
+    int64_t numStages, const int64_t *Stagingp, const int64_t *StageMap,
+    size_t gpuMemorySize, int *status
+)
+{
+    int dummy ;
+    if (!status) status = &dummy ;
+    *status = 0 ;
+    if (m < 0 || n < 0 || anz < 0 || nf < 0 || !Sp || !Sleft || !Super || !Rp || !Parent || !Childp || !Child
+        || !Post || !Fm || !Cm || !RimapOffsets || !RjmapOffsets || !Stagingp || !StageMap
+        || (anz > 0 && !Sj) || (nf > 0 && Rp [nf] > 0 && !Rj) || numStages < 0)
+    {
+        *status = 3 ;
+        return NULL ;
+    }
+    // the checks the driver's indexing relies on
+    if (Sp [m] != anz || Super [nf] > n) { *status = 3 ; return NULL ; }
+    for (Long f = 0 ; f < nf ; f++)
+    {
+        const Long fp = Super [f+1] - Super [f], fn = Rp [f+1] - Rp [f] ;
+        if (fp < 0 || fn < fp || Fm [f] < 0 || Cm [f] < 0 || Cm [f] > fn - fp || Cm [f] > Fm [f]
+            || Parent [f] <= f || Parent [f] > nf || StageMap [f] < 0 || StageMap [f] > numStages
+            || Post [f] < 0 || Post [f] >= nf)
+        {
+            *status = 3 ;
+            return NULL ;
+        }
+    }
+    for (Long k = 0 ; k < anz ; k++) if (Sj [k] < 0) { *status = 3 ; return NULL ; }
+    spqr_amd_symbolic *S = NULL ;
+    try
+    {
+        S = new spqr_amd_symbolic ( ) ;
+        { static std::atomic<uint64_t> next_uid ((uint64_t) 1 << 40) ; S->uid = next_uid.fetch_add (1) ; }
+        S->m = m ; S->n = n ; S->anz = anz ; S->nf = nf ;
+        S->Sp.assign (Sp, Sp + m + 1) ;
+        S->Sj.assign (Sj, Sj + anz) ;
+        S->Sleft.assign (Sleft, Sleft + n + 2) ;
+        S->Super.assign (Super, Super + nf + 1) ;
+        S->Rp.assign (Rp, Rp + nf + 1) ;
+        S->rjsize = Rp [nf] ;
+        S->Rj.assign (Rj, Rj + S->rjsize) ;
+        S->Parent.assign (Parent, Parent + nf + 1) ;
+        S->Childp.assign (Childp, Childp + nf + 2) ;
+        S->Child.assign (Child, Child + nf + 1) ;
+        S->Post.assign (Post, Post + nf) ;
+        S->Post.push_back (nf) ;
+        S->Fm.assign (Fm, Fm + nf) ; S->Fm.push_back (0) ;
+        S->Cm.assign (Cm, Cm + nf) ; S->Cm.push_back (0) ;
+        S->RimapOffsets.assign (RimapOffsets, RimapOffsets + nf) ; S->RimapOffsets.push_back (RimapSize) ;
+        S->RjmapOffsets.assign (RjmapOffsets, RjmapOffsets + nf) ; S->RjmapOffsets.push_back (RjmapSize) ;
+        S->RimapSize = RimapSize ; S->RjmapSize = RjmapSize ;
+        S->numStages = numStages ;
+        S->Stagingp.assign (Stagingp, Stagingp + numStages + 1) ;
+        S->Stagingp.resize ((size_t) nf + 2, nf) ;
+        S->StageMap.assign (StageMap, StageMap + nf) ; S->StageMap.push_back (0) ;
+        S->gpuMemorySize = gpuMemorySize ;
+        for (Long f = 0 ; f < nf ; f++)
+        {
+            const Long fn = Rp [f+1] - Rp [f], rm = std::min (Fm [f], Super [f+1] - Super [f]) ;
+            S->maxfn = std::max (S->maxfn, fn) ;
+            S->rnz += rm*(rm+1)/2 + rm*(fn-rm) ;
+        }
+        return S ;
+    }
+    catch (std::bad_alloc &)
+    {
+        delete S ;
+        *status = 1 ;
+        return NULL ;
+    }
+}
+
 extern "C" void spqr_amd_symbolic_free (spqr_amd_symbolic *sym)
 {
     delete sym ;

@@ -263,10 +263,14 @@ static int build_numeric_cache (const spqr_amd_symbolic *S, const int64_t *Ap, c
     spqr_amd_symbolic::NumericCache &C = S->cache ;
     int dev = -1 ;
     if (hipGetDevice (&dev) != hipSuccess) return 2 ;
-    if (Ap [S->n] != S->anz) return 3 ;             // not the matrix that was analysed
+    // Ap == NULL: the caller hands the values of S = A(P,Q) in row form (SPQR's Sx, made by
+    // spqr_stranspose2), which are in the symbolic object's own order.
+    const bool from_sx = (Ap == NULL) ;
+    if (!from_sx && Ap [S->n] != S->anz) return 3 ;             // not the matrix that was analysed
+    if (!from_sx && ((Long) S->Qfill.size ( ) < S->n || (Long) S->PLinv.size ( ) < S->m)) return 3 ;   // made from arrays: Sx only
     // The cache is derived from the pattern of the first matrix factorized with this object: a later
     // call with another pattern (same size or not) must not reuse it silently.
-    const uint64_t fp = pattern_fingerprint (Ap, Ai, S->n, S->anz) ;
+    const uint64_t fp = from_sx ? 0x5358ull : pattern_fingerprint (Ap, Ai, S->n, S->anz) ;
     if (C.built && C.device == dev && C.pattern == fp) return 0 ;
     if (C.built) release_numeric_cache (&C) ;
     C.pattern = fp ;
@@ -276,6 +280,11 @@ static int build_numeric_cache (const spqr_amd_symbolic *S, const int64_t *Ap, c
     // position in Ax of every entry of S = A(P,Q) in row form (spqr_stranspose2's scatter)
     hostvec<Long> sxperm ((size_t) std::max ((Long) 1, anz)) ;
     hostvec<double> Sx ((size_t) std::max ((Long) 1, anz)) ;
+    if (from_sx)
+    {
+        for (Long q = 0 ; q < anz ; q++) { sxperm [q] = q ; Sx [q] = (double) q ; }
+    }
+    else
     {
         hostvec<Long> w (Sp, Sp + m) ;
         for (Long k = 0 ; k < n ; k++)
@@ -324,7 +333,7 @@ static int build_numeric_cache (const spqr_amd_symbolic *S, const int64_t *Ap, c
 extern "C" void spqr_amd_numeric_free (spqr_amd_numeric *num)
 {
     if (!num) return ;
-    if (num->Rstack) { if (num->RstackPinned) (void) hipHostFree (num->Rstack) ; else host_free (num->Rstack) ; }
+    if (num->Rstack && !num->RstackBorrowed) { if (num->RstackPinned) (void) hipHostFree (num->Rstack) ; else host_free (num->Rstack) ; }
     host_free (num->Rblock) ; host_free (num->Rdead) ; host_free (num->Cstack) ; host_free (num->Cblock) ;
     host_free (num) ;
 }
@@ -442,9 +451,11 @@ static int factorize_impl
 (
     const spqr_amd_symbolic *S, const int64_t *Ap, const int64_t *Ai, const double *Ax,
     const char *mine, const double *const *limbo_in, const bool limbo_in_dev, double *c_out_dev,
+    double *Rstack_user, int64_t Rstack_room,
     spqr_amd_numeric **num_out
 )
 {
+    // Ap == NULL: Ax holds the values of S in row form (see build_numeric_cache)
     *num_out = NULL ;
     int code = 0 ;
     const bool verbose = getenv ("GPUQR_VERBOSE") != NULL ;
@@ -471,6 +482,7 @@ static int factorize_impl
     hostvec<double *> limbo ;           // contribution blocks waiting on the host for a later group
     hostvec<double *> limbo_dev ;       // ... or on the device, when it has the room (no PCIe round trip)
     hostvec<double *> used_dev ;        // device limbo blocks consumed by the running group
+    bool registered = false ;           // the caller's stack was page-locked by this call
 
     try
     {
@@ -493,6 +505,19 @@ static int factorize_impl
         num->rsize = rtotal ;
         // pinned, so that the packed R arrives by DMA; pageable if the system refuses that much pinned memory
         num->RstackPinned = 1 ;
+        if (Rstack_user)
+        {
+            // the caller's stack (SPQR's Work[0].Stack_head): page-locked in place for the duration of
+            // the call when the system allows it, filled through bounce buffers otherwise
+            if (Rstack_room < rtotal) { code = 1 ; goto done ; }
+            num->Rstack = Rstack_user ;
+            num->RstackBorrowed = 1 ;
+            if (rtotal > 0 && getenv ("GPUQR_PAGEABLE_R") == NULL
+                && hipHostRegister (Rstack_user, (size_t) rtotal * sizeof (double), hipHostRegisterDefault) == hipSuccess)
+                registered = true ;
+            else { (void) hipGetLastError ( ) ; num->RstackPinned = 0 ; }
+        }
+        else
         if (getenv ("GPUQR_PAGEABLE_R") != NULL       // test knob: take the fallback path
             || hipHostMalloc ((void **) &num->Rstack, (size_t) std::max ((Long) 1, rtotal) * sizeof (double), hipHostMallocDefault) != hipSuccess)
         {
@@ -918,6 +943,7 @@ static int factorize_impl
 
 done:
     if (join_r ( ) != hipSuccess && code == 0) code = 2 ;
+    if (registered) { (void) hipHostUnregister (Rstack_user) ; num->RstackPinned = 0 ; }
     for (size_t i = 0 ; i < limbo.size ( ) ; i++) host_free (limbo [i]) ;
     for (size_t i = 0 ; i < limbo_dev.size ( ) ; i++) if (limbo_dev [i]) (void) hipFree (limbo_dev [i]) ;
     for (size_t i = 0 ; i < used_dev.size ( ) ; i++) (void) hipFree (used_dev [i]) ;
@@ -934,7 +960,38 @@ extern "C" int spqrgpu_amd_factorize
 )
 {
     if (!S || !Ap || !Ax || !num_out || (!Ai && S->anz > 0)) return 3 ;
-    return factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, num_out) ;
+    return factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, num_out) ;
+}
+
+// What SPQR's numeric phase hands to spqrgpu_kernel and takes back from it, on plain arrays
+// (SPQR/SPQRGPU/spqrgpu_kernel.cpp:63-782): Sx are the values of S = A(P,Q) in row form
+// (Blob->Sx); the R blocks are written column-packed, front after front in postorder, stage after
+// stage, starting at Stack_head (Work[0].Stack_head), and Rblock_offset[f] says where front f's
+// block begins relative to it (the adapter turns that into QRnum->Rblock[f]); Rdead[k] is set to 1
+// for pivot columns past the bottom of their front (entries are only ever set, never cleared).
+extern "C" int spqrgpu_amd_kernel
+(
+    const spqr_amd_symbolic *S, const double *Sx,
+    double *Stack_head, int64_t stack_room,
+    int64_t *Rblock_offset, char *Rdead,
+    int64_t *sumfrank, int64_t *maxfrank, int64_t *stack_used,
+    double *gpuKernelTime, int64_t *gpuFlops, int64_t *gpuNumKernelLaunches
+)
+{
+    if (!S || (!Sx && S->anz > 0) || (!Stack_head && S->rnz > 0) || !Rblock_offset || !Rdead) return 3 ;
+    spqr_amd_numeric *num = NULL ;
+    const int code = factorize_impl (S, NULL, NULL, Sx, NULL, NULL, false, NULL, Stack_head, stack_room, &num) ;
+    if (code != 0) return code ;
+    for (Long f = 0 ; f < S->nf ; f++) Rblock_offset [f] = num->Rblock [f] ;
+    for (Long k = 0 ; k < S->n ; k++) if (num->Rdead [k]) Rdead [k] = 1 ;
+    if (sumfrank) *sumfrank = num->sumfrank ;
+    if (maxfrank) *maxfrank = num->maxfrank ;
+    if (stack_used) *stack_used = num->rsize ;
+    if (gpuKernelTime) *gpuKernelTime = num->gpuKernelTime ;
+    if (gpuFlops) *gpuFlops = num->gpuFlops ;
+    if (gpuNumKernelLaunches) *gpuNumKernelLaunches = num->gpuNumKernelLaunches ;
+    spqr_amd_numeric_free (num) ;
+    return 0 ;
 }
 
 // R blocks -> compressed-column R (the R-only part of spqr_rcount / spqr_rconvert,
@@ -1004,7 +1061,7 @@ extern "C" int spqrgpu_amd_factorize_subset
 )
 {
     if (!S || !Ap || !Ax || !mine || !num_out || (!Ai && S->anz > 0)) return 3 ;
-    return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in, false, NULL, num_out) ;
+    return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in, false, NULL, NULL, 0, num_out) ;
 }
 
 // The same with the contribution blocks staying on the device on both sides: limbo_in[c] are device
@@ -1019,7 +1076,7 @@ extern "C" int spqrgpu_amd_factorize_subset_dev
 {
     if (!S || !Ap || !Ax || !mine || !num_out || (!Ai && S->anz > 0)) return 3 ;
     if (!c_out_dev && spqrgpu_amd_subset_csize (S, mine) > 0) return 3 ;
-    return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in_dev, true, c_out_dev, num_out) ;
+    return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in_dev, true, c_out_dev, NULL, 0, num_out) ;
 }
 
 // Doubles of contribution blocks that leave a subset call: the fronts of the subset whose parent is

@@ -26,7 +26,8 @@ class Numeric(C.Structure):
                 ("gpuFlops", C.c_int64), ("gpuNumKernelLaunches", C.c_int64),
                 ("numStagesRun", C.c_int64), ("assembleBytes", C.c_double),
                 ("Cstack", C.POINTER(C.c_double)), ("Cblock", C.POINTER(C.c_int64)),
-                ("RstackPinned", C.c_int64), ("csize", C.c_int64)]
+                ("RstackPinned", C.c_int64), ("csize", C.c_int64),
+                ("RstackBorrowed", C.c_int64)]
 
 
 _ARRAYS = ["Qfill", "PLinv", "Sleft", "Sp", "Sj", "Super", "Rp", "Rj", "Parent", "Childp", "Child",
@@ -94,7 +95,9 @@ def analyze(A, Q=None, relax=0, gpuMemorySize=0):
     h = L.spqr_amd_analyze(m, n, _p(Ap), _p(Ai), _p(Qa), relax, gpuMemorySize, C.byref(st))
     if not h:
         raise MemoryError("spqr_amd_analyze failed, status %d" % st.value)
-    return Symbolic(h, st.value)
+    sym = Symbolic(h, st.value)
+    sym.gpuMemorySize = gpuMemorySize
+    return sym
 
 
 class NumericResult:
@@ -218,3 +221,47 @@ def qr_solve(A, B, Q=None, relax=0, gpuMemorySize=2**34):
     x = np.zeros((n, k))
     x[sym.Qfill[:n]] = y                                   # R is the factor of A(:,Qfill)
     return x, R, sym
+
+
+def symbolic_from_arrays(sym, gpuMemorySize=None):
+    """spqr_amd_symbolic_from_arrays on the arrays of an existing Symbolic (or any object with the same
+    attribute names, e.g. arrays dumped from an SPQR run): the object an SPQR build makes from QRsym."""
+    L = _bind()
+    nf = int(sym.nf)
+    a = {k: _i64(getattr(sym, k)) for k in ("Sp", "Sj", "Sleft", "Super", "Rp", "Rj", "Parent", "Childp", "Child",
+                                             "Post", "Fm", "Cm", "RimapOffsets", "RjmapOffsets", "Stagingp", "StageMap")}
+    L.spqr_amd_symbolic_from_arrays.restype = C.c_void_p
+    L.spqr_amd_symbolic_from_arrays.argtypes = ([C.c_int64] * 4 + [C.c_void_p] * 13 + [C.c_int64, C.c_void_p, C.c_int64,
+                                                C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)])
+    st = C.c_int(0)
+    mem = int(gpuMemorySize if gpuMemorySize is not None else getattr(sym, "gpuMemorySize", 2**34))
+    h = L.spqr_amd_symbolic_from_arrays(
+        int(sym.m), int(sym.n), int(sym.anz), nf, _p(a["Sp"]), _p(a["Sj"]), _p(a["Sleft"]), _p(a["Super"]), _p(a["Rp"]),
+        _p(a["Rj"]), _p(a["Parent"]), _p(a["Childp"]), _p(a["Child"]), _p(a["Post"]), _p(a["Fm"]), _p(a["Cm"]),
+        _p(a["RimapOffsets"]), int(sym.RimapSize), _p(a["RjmapOffsets"]), int(sym.RjmapSize),
+        int(sym.numStages), _p(a["Stagingp"]), _p(a["StageMap"]), mem, C.byref(st))
+    if not h:
+        raise ValueError("spqr_amd_symbolic_from_arrays failed, status %d" % st.value)
+    return Symbolic(h, st.value)
+
+
+def spqrgpu_kernel(sym, Sx, stack_room=None):
+    """spqrgpu_amd_kernel: the body of the reference's spqrgpu_kernel (SPQR/SPQRGPU/spqrgpu_kernel.cpp:63-782)
+    on plain arrays.  Returns dict(code, stack (the R blocks as laid on the caller's stack), Rblock, Rdead,
+    sumfrank, maxfrank, used, kernel_ms, flops, launches)."""
+    L = _bind()
+    nf, n = int(sym.nf), int(sym.n)
+    Sx = None if Sx is None else np.ascontiguousarray(Sx, dtype=np.float64)
+    room = int(sym.rnz if stack_room is None else stack_room)
+    stack = np.zeros(max(room, 1))
+    Rblock = np.full(max(nf, 1), -1, np.int64)
+    Rdead = np.zeros(max(n, 1), np.int8)
+    sumfrank, maxfrank, used, flops, launches = (C.c_int64(0) for _ in range(5))
+    kms = C.c_double(0)
+    L.spqrgpu_amd_kernel.restype = C.c_int
+    L.spqrgpu_amd_kernel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p] + [
+        C.POINTER(C.c_int64)] * 3 + [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    code = L.spqrgpu_amd_kernel(sym._h, _p(Sx), _p(stack), room, _p(Rblock), _p(Rdead), C.byref(sumfrank),
+                                C.byref(maxfrank), C.byref(used), C.byref(kms), C.byref(flops), C.byref(launches))
+    return dict(code=code, stack=stack, Rblock=Rblock, Rdead=Rdead, sumfrank=sumfrank.value, maxfrank=maxfrank.value,
+                used=used.value, kernel_ms=kms.value, flops=flops.value, launches=launches.value)

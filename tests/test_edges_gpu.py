@@ -125,6 +125,61 @@ def test_failing_host_allocator_reports_out_of_memory():
     assert ss.GPUQREngine(0, fronts, 1) == ss.QRENGINE_SUCCESS
 
 
+def test_failing_host_allocator_reaches_the_spqr_glue():
+    """The reference routes every host allocation through SuiteSparse_config's table so that its
+    failing-allocator tests bite (SPQR/Tcov/qrtest.cpp:58-140).  Here: the numeric driver under an
+    allocator that refuses after N calls returns out-of-memory (1) for small N, succeeds for large N,
+    leaves no half-built cache behind, and the result afterwards is the usual one."""
+    from suitesparse_amd import problems, spqr
+    L = _lib.lib()
+    MALLOC = C.CFUNCTYPE(C.c_void_p, C.c_size_t)
+    CALLOC = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_size_t)
+    FREE = C.CFUNCTYPE(None, C.c_void_p)
+    libc = C.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes = C.c_void_p, [C.c_size_t]
+    libc.calloc.restype, libc.calloc.argtypes = C.c_void_p, [C.c_size_t, C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    budget = {"n": 0, "calls": 0}
+
+    def my_malloc(sz):
+        budget["n"] -= 1
+        budget["calls"] += 1
+        return None if budget["n"] < 0 else libc.malloc(sz)
+
+    def my_calloc(a, b):
+        budget["n"] -= 1
+        budget["calls"] += 1
+        return None if budget["n"] < 0 else libc.calloc(a, b)
+
+    cbs = (MALLOC(my_malloc), CALLOC(my_calloc), FREE(lambda p: libc.free(p)))
+    L.gpuqr_set_allocator.argtypes = [MALLOC, CALLOC, FREE]
+    A = problems.stacked_ls((12, 12))
+    Q = problems.nested_dissection((12, 12), leaf=3)
+    good = spqr.factorize(spqr.analyze(A, Q, gpuMemorySize=2**33), A)
+    codes = []
+    try:
+        for allowed in list(range(0, 40, 3)) + [10**6]:
+            sym = spqr.analyze(A, Q, gpuMemorySize=2**33)        # a fresh object: the pattern cache is rebuilt
+            budget["n"], budget["calls"] = allowed, 0
+            L.gpuqr_set_allocator(*cbs)
+            try:
+                res = spqr.factorize(sym, A)
+                codes.append(0)
+                assert (res.R != good.R).nnz == 0
+            except RuntimeError as e:
+                codes.append(int(str(e).split()[-1]))
+            finally:
+                L.gpuqr_set_allocator(MALLOC(0), CALLOC(0), FREE(0))
+            if allowed == 10**6:
+                assert budget["calls"] > 20                  # the glue's allocations do go through the hooks
+    finally:
+        L.gpuqr_set_allocator(MALLOC(0), CALLOC(0), FREE(0))
+    assert codes[0] == 1 and codes[-1] == 0
+    assert set(codes) <= {0, 1}
+    res = spqr.factorize(spqr.analyze(A, Q, gpuMemorySize=2**33), A)
+    assert (res.R != good.R).nnz == 0
+
+
 def test_repeated_device_batches_reuse_the_schedule_and_follow_the_values():
     """The engine recognises a repeated problem description (same shapes, buffers, staircases) and
     replays its schedule; the factors must follow the new values, and a different batch in between

@@ -207,3 +207,38 @@ def test_cpp_shim_compiles_and_links():
     subprocess.check_call(["make", "-s", "-C", d])
     out = subprocess.check_output([os.path.join(d, "demo_dense"), "linkcheck"]).decode()
     assert "compiled and linked" in out
+
+
+def test_symbolic_from_arrays_round_trip_and_validation():
+    """The constructor an SPQR build uses (arrays of QRsym / QRsym->QRgpu in, symbolic object out):
+    every array comes back as given; inconsistent input is refused; nothing here needs a GPU."""
+    A = problems.stacked_ls((10, 10))
+    sym = spqr.analyze(A, problems.nested_dissection((10, 10), leaf=3), gpuMemorySize=2**33)
+    sym2 = spqr.symbolic_from_arrays(sym)
+    assert (sym2.m, sym2.n, sym2.anz, sym2.nf, sym2.maxfn, sym2.rnz) == (sym.m, sym.n, sym.anz, sym.nf, sym.maxfn, sym.rnz)
+    nf = sym.nf
+    for name, ln in (("Sp", sym.m + 1), ("Sj", sym.anz), ("Sleft", sym.n + 2), ("Super", nf + 1), ("Rp", nf + 1),
+                     ("Rj", int(sym.Rp[nf])), ("Parent", nf + 1), ("Childp", nf + 2), ("Child", nf + 1), ("Post", nf),
+                     ("Fm", nf), ("Cm", nf), ("RimapOffsets", nf), ("RjmapOffsets", nf), ("StageMap", nf),
+                     ("Stagingp", sym.numStages + 1)):
+        assert np.array_equal(getattr(sym2, name)[:ln], getattr(sym, name)[:ln]), name
+    assert (sym2.RimapSize, sym2.RjmapSize, sym2.numStages) == (sym.RimapSize, sym.RjmapSize, sym.numStages)
+
+    class Bad:
+        pass
+    bad = Bad()
+    bad.__dict__.update({k: getattr(sym, k) for k in ("m", "n", "anz", "nf", "RimapSize", "RjmapSize", "numStages",
+                                                      "Sp", "Sj", "Sleft", "Super", "Rp", "Rj", "Parent", "Childp", "Child",
+                                                      "Post", "Fm", "Cm", "RimapOffsets", "RjmapOffsets", "Stagingp",
+                                                      "StageMap")})
+    bad.Parent = sym.Parent.copy()
+    bad.Parent[0] = 0                                   # a front cannot be its own parent
+    with pytest.raises(ValueError):
+        spqr.symbolic_from_arrays(bad, 2**33)
+    bad.Parent = sym.Parent
+    bad.Cm = sym.Cm.copy()
+    bad.Cm[0] = 10**6                                   # a contribution block taller than its front
+    with pytest.raises(ValueError):
+        spqr.symbolic_from_arrays(bad, 2**33)
+    # (argument validation happens before any device call)
+    assert spqr.spqrgpu_kernel(sym2, None)["code"] == 3

@@ -322,3 +322,36 @@ def test_config5_dependent_columns_show_on_the_diagonal():
     assert np.linalg.matrix_rank(AQ, tol=tol) == n - 24
     # the dead ones are the appended copies (they come last in the column order)
     assert set(np.nonzero(dead)[0]) == set(np.nonzero(sym.Qfill >= n0)[0])
+
+
+@pytest.mark.parametrize("mem", [2**34, 14_000_000, 0])
+@pytest.mark.parametrize("pageable", [False, True])
+def test_spqr_binding_from_arrays_gives_the_same_r(mem, pageable, monkeypatch):
+    """What an SPQR build does (adapter/spqrgpu_kernel.cpp): the symbolic object from QRsym's arrays,
+    the values as Sx, R written onto the caller's stack.  Same bits as the direct path; same stage
+    count; the stack head moves by exactly nnz of the R blocks."""
+    if pageable:
+        monkeypatch.setenv("GPUQR_PAGEABLE_R", "1")
+    shape = (9, 9, 9)
+    A = problems.stacked_ls(shape)
+    Q = problems.nested_dissection(shape, leaf=2)
+    sym = spqr.analyze(A, Q, relax=20, gpuMemorySize=mem)
+    direct = spqr.factorize(sym, A)
+    sym2 = spqr.symbolic_from_arrays(sym)
+    out = spqr.spqrgpu_kernel(sym2, spqr.s_values(sym, A), stack_room=sym.rnz + 7)
+    assert out["code"] == 0
+    assert out["used"] == sym.rnz and out["sumfrank"] == direct.rank and out["maxfrank"] == direct.maxfrank
+    assert np.array_equal(out["Rdead"][:sym.n], direct.Rdead)
+    assert np.all(out["stack"][sym.rnz:] == 0)                  # nothing written past the blocks
+    # blocks lie in postorder, stage after stage (spqrgpu_kernel.cpp:399-440)
+    order = np.argsort(out["Rblock"][:sym.nf])
+    assert np.array_equal(order, sym.Post[:sym.nf])
+    from suitesparse_amd import multigpu
+    Rb = {}
+    for f in range(sym.nf):
+        sz = multigpu._r_size(sym, f)
+        Rb[f] = out["stack"][out["Rblock"][f]:out["Rblock"][f] + sz]
+    R = multigpu.blocks_to_csc(sym, Rb)
+    assert R.shape == direct.R.shape and (R != direct.R).nnz == 0
+    # too little room on the stack is refused
+    assert spqr.spqrgpu_kernel(sym2, spqr.s_values(sym, A), stack_room=sym.rnz - 1)["code"] == 1
