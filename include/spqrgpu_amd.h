@@ -72,6 +72,16 @@ spqr_amd_symbolic *spqr_amd_analyze
     int relax, size_t gpuMemorySize, int *status
 );
 
+/* The same analysis with SPQR's do_rank_detection switch (SPQR/Source/spqr_analyze.cpp:75-125,826-842):
+ * when it is on, Cm[f] = min (fm, cn) and Fm is sized for it, so that a front whose pivot columns
+ * die at a tolerance has room to pass the freed rows up.  spqrgpu_amd_factorize_tol needs an object
+ * analysed this way. */
+spqr_amd_symbolic *spqr_amd_analyze_rd
+(
+    int64_t m, int64_t n, const int64_t *Ap, const int64_t *Ai, const int64_t *Quser,
+    int relax, size_t gpuMemorySize, int do_rank_detection, int *status
+);
+
 void spqr_amd_symbolic_free (spqr_amd_symbolic *sym);
 
 /* The symbolic object of an SPQR build: the arrays spqrgpu_kernel reads out of QRsym and
@@ -124,6 +134,7 @@ typedef struct spqr_amd_numeric
     int64_t  RstackPinned;  /* 1: Rstack is pinned host memory; 0: the pinned allocation was refused and it is pageable */
     int64_t  csize;         /* subset driver: doubles of contribution blocks that left (in Cstack or the caller's device buffer) */
     int64_t  RstackBorrowed;/* 1: Rstack is the caller's memory (spqrgpu_amd_kernel) and is not freed with the object */
+    int64_t  numPasses;     /* spqrgpu_amd_factorize_tol: factorization passes it took (1: no dead column found) */
 } spqr_amd_numeric;
 
 /* Replaces void spqrgpu_kernel (spqr_blob <double> *Blob)
@@ -135,6 +146,19 @@ int spqrgpu_amd_factorize (const spqr_amd_symbolic *sym, const int64_t *Ap, cons
                            const double *Ax, spqr_amd_numeric **num_out);
 
 void spqr_amd_numeric_free (spqr_amd_numeric *num);
+
+/* Numeric factorization with SPQR's rank detection at tolerance tol on the device: what the
+ * reference's CPU path does in spqr_front (SPQR/Source/spqr_front.cpp:424-479: a pivot column whose
+ * remaining norm is <= tol is dead, Rdead[k] = 1, and does not use up a row, so R comes out squeezed
+ * with `rank` rows) and what its GPU path declines to do (SPQR/Source/spqr_analyze.cpp:106-125 turns
+ * the GPU off when tol >= 0).  sym must come from spqr_amd_analyze_rd with do_rank_detection = 1.
+ * On return num->Rdead flags the dead pivot columns, num->sumfrank is the numerical rank, and the R
+ * blocks are squeezed and column-packed as SPQR's (spqr_amd_rconvert reads them).  tol < 0 means no
+ * rank detection (SPQR_NO_TOL); spqr_amd_default_tol gives SPQR_DEFAULT_TOL
+ * (SPQR/Source/spqr_tol.cpp:14-27).  Returns 0, 1 out of memory, 2 GPU problem, 3 invalid argument. */
+int spqrgpu_amd_factorize_tol (const spqr_amd_symbolic *sym, const int64_t *Ap, const int64_t *Ai,
+                               const double *Ax, double tol, spqr_amd_numeric **num_out);
+double spqr_amd_default_tol (int64_t m, int64_t n, const int64_t *Ap, const double *Ax);
 
 /* The body of void spqrgpu_kernel (spqr_blob <double> *Blob) on plain arrays
  * (SPQR/Include/spqrgpu.hpp:9-14, SPQR/SPQRGPU/spqrgpu_kernel.cpp:63-782; adapter/spqrgpu_kernel.cpp

@@ -210,3 +210,54 @@ def multifrontal_lapack(sym, Sx, keep_R=True):
         if int(sym.Parent[f]) < nf and cm * cn > 0:
             Cblk[f] = np.triu(qr[rk:rk + cm, fp:])
     return Rb, t_qr, time.perf_counter() - t_all
+
+
+def multifrontal_tol(sym, Sx, tol):
+    """CPU multifrontal QR with SPQR's rank detection (oracle_multifrontal_tol restates
+    SPQR/Source/spqr_front.cpp:356-479 and spqr_kernel.cpp:134-321).  sym must come from an analysis with
+    rank detection allowed.  Returns (R scipy CSC rank-by-n squeezed, explicit zeros kept, Rdead, rank, per-front ranks, norm_E_fro)."""
+    nf, n = sym.nf, sym.n
+    Stair, Rjmap, Rimap, cpuS = build_assembly_maps(sym, Sx)
+    fn = np.diff(_i64(sym.Rp))[:nf]
+    FOff = np.zeros(nf + 1, np.int64)
+    FOff[1:] = np.cumsum(_i64(sym.Fm)[:nf] * fn)
+    Scount = np.array([sym.Sp[sym.Sleft[sym.Super[f + 1]]] - sym.Sp[sym.Sleft[sym.Super[f]]] for f in range(nf)],
+                      dtype=np.int64)
+    SOff = np.zeros(nf + 1, np.int64)
+    post = _i64(sym.Post)[:nf]
+    SOff[post] = np.concatenate([[0], np.cumsum(Scount[post])[:-1]]) if nf > 0 else 0
+    Farena = np.zeros(max(int(FOff[nf]), 1))
+    Rdead = np.zeros(max(n, 1), np.int8)
+    Rank = np.zeros(max(nf, 1), np.int64)
+    enorm = C.c_double(0)
+    f = lib().oracle_multifrontal_tol
+    f.restype = None
+    f.argtypes = [C.c_int64] + [C.c_void_p] * 16 + [C.c_double, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    f(nf, _p(post), _p(_i64(sym.Parent)), _p(_i64(sym.Super)), _p(_i64(sym.Rp)), _p(_i64(sym.Fm)),
+      _p(_i64(sym.Cm)), _p(_i64(sym.Sleft)), _p(_i64(sym.Sp)), _p(Rjmap), _p(_i64(sym.RjmapOffsets)),
+      _p(Rimap), _p(_i64(sym.RimapOffsets)), _p(cpuS), _p(FOff), _p(SOff), _p(Farena),
+      float(tol), _p(Rdead), _p(Rank), C.byref(enorm))
+    import scipy.sparse as sp
+    rank = int(Rank[:nf].sum())
+    ri, ci, vals = [], [], []
+    row1 = 0
+    for fr in range(nf):
+        fm = int(sym.Fm[fr])
+        col1, fp = int(sym.Super[fr]), int(sym.Super[fr + 1] - sym.Super[fr])
+        cols = _i64(sym.Rj)[sym.Rp[fr]:sym.Rp[fr + 1]]
+        fnn = cols.size
+        F = Farena[FOff[fr]:FOff[fr] + fm * fnn].reshape(fm, fnn)
+        rm = 0
+        for k in range(fnn):
+            if k < fp and not Rdead[col1 + k] and rm < fm:
+                rm += 1
+            if rm > 0:
+                ri.append(np.arange(row1, row1 + rm))
+                ci.append(np.full(rm, cols[k]))
+                vals.append(F[:rm, k].copy())
+        row1 += int(Rank[fr])
+    if ri:
+        R = sp.csc_matrix((np.concatenate(vals), (np.concatenate(ri), np.concatenate(ci))), shape=(rank, n))
+    else:
+        R = sp.csc_matrix((rank, n))
+    return R, Rdead[:n].copy(), rank, Rank[:nf].copy(), float(enorm.value)

@@ -343,3 +343,134 @@ void oracle_front_qr_batch (double *F, const Long *fm, const Long *fn, Long nfro
     for (Long k = 0 ; k < nfronts ; k++) oracle_front_qr (F + off [k], fm [k], fn [k], NULL) ;
     free (off) ;
 }
+
+/* ---------------------------------------------------------------------------
+ * rank detection: the CPU path's dead-column rule
+ * ------------------------------------------------------------------------- */
+
+/* Householder QR of a front with SPQR's rank detection, restating
+ * SPQR/Source/spqr_front.cpp:356-479 one reflection at a time (its fchunk <= 1
+ * path; the blocked path applies the same reflections later): g is the row of
+ * the next pivot; column k is reduced over rows g..fm-1; if k is one of the
+ * first npiv (pivot) columns and the resulting |R(g,k)| = norm (F (g:fm-1,k)) is
+ * <= tol, the column is dead: it is zeroed from row g down, Rdead [k] = 1 and g
+ * does NOT advance, so the next live column pivots on the same row (R comes out
+ * "squeezed", spqr_front.cpp:424-479).  Pivot columns that are reached after the
+ * rows have run out (g == fm) are dead as well (spqr_front.cpp:334-354).  The
+ * reflection itself follows the device convention above (R(g,k) >= 0), which
+ * differs from LAPACK's dlarfg only in the sign of a row of R.  Row-major
+ * fm-by-fn front; returns the number of live pivot columns (the rank of the
+ * front's R block); non-pivot columns are reduced too, so that the contribution
+ * block below row `rank` comes out upper trapezoidal.  Dead-column 2-norms are
+ * accumulated into *wssq as a plain sum of squares (spqr_front keeps a scaled
+ * sum, :434-452, for the same quantity). */
+Long oracle_front_qr_tol (double *F, Long fm, Long fn, Long npiv, double tol, char *Rdead, double *wssq)
+{
+    double *v = (double *) malloc ((size_t) (fm > 0 ? fm : 1) * sizeof (double)) ;
+    double *z = (double *) malloc ((size_t) (fn > 0 ? fn : 1) * sizeof (double)) ;
+    Long g = 0, rank = 0 ;
+    if (npiv > fn) npiv = fn ;
+    for (Long k = 0 ; k < fn ; k++)
+    {
+        if (k == npiv) rank = g ;
+        if (g >= fm)
+        {
+            /* hit the wall: no rows left */
+            if (k < npiv) Rdead [k] = 1 ;
+            continue ;
+        }
+        double sigma = 0 ;
+        for (Long i = g+1 ; i < fm ; i++) sigma += F [i*fn+k] * F [i*fn+k] ;
+        double x1 = F [g*fn+k] ;
+        double s, v1, tau ;
+        if (sigma <= 1e-90)
+        {
+            s = x1 ; v1 = 0 ; tau = 0 ;
+        }
+        else
+        {
+            s = sqrt (x1*x1 + sigma) ;
+            v1 = (x1 <= 0) ? (x1 - s) : (-sigma / (x1 + s)) ;
+            tau = -1 / (s * v1) ;
+        }
+        if (k < npiv && tol >= 0 && fabs (s) <= tol)
+        {
+            /* dead column: flag it, drop what is left of it, keep the pivot row for the next one */
+            if (wssq) *wssq += s*s ;
+            for (Long i = g ; i < fm ; i++) F [i*fn+k] = 0 ;
+            Rdead [k] = 1 ;
+            continue ;
+        }
+        v [g] = v1 ;
+        for (Long i = g+1 ; i < fm ; i++) v [i] = F [i*fn+k] ;
+        F [g*fn+k] = s ;
+        for (Long i = g+1 ; i < fm ; i++) F [i*fn+k] = 0 ;
+        if (tau != 0)
+        {
+            for (Long j = k+1 ; j < fn ; j++) z [j] = 0 ;
+            for (Long i = g ; i < fm ; i++)
+            {
+                const double vi = v [i] ;
+                const double *Fi = F + i*fn ;
+                for (Long j = k+1 ; j < fn ; j++) z [j] += vi * Fi [j] ;
+            }
+            for (Long j = k+1 ; j < fn ; j++) z [j] *= -tau ;
+            for (Long i = g ; i < fm ; i++)
+            {
+                const double vi = v [i] ;
+                double *Fi = F + i*fn ;
+                for (Long j = k+1 ; j < fn ; j++) Fi [j] += vi * z [j] ;
+            }
+        }
+        g++ ;
+    }
+    if (npiv >= fn) rank = g ;
+    free (z) ;
+    free (v) ;
+    return rank ;
+}
+
+/* The whole tree with rank detection, as spqr_kernel drives spqr_front
+ * (SPQR/Source/spqr_kernel.cpp:134-321): per front, assemble, factorize with tol
+ * over the front's pivot columns, hand the rows below the front's rank (at most
+ * cn of them: the contribution block, spqr_cpack) to the parent.  The symbolic
+ * object must come from an analysis with rank detection allowed, i.e. Cm [f] =
+ * min (fm, cn) and Fm sized for it (SPQR/Source/spqr_analyze.cpp:826-842), so that
+ * a parent has a row for every row a child may pass up; rows a child does not
+ * use stay zero.  Rdead has one entry per column of S (pivot k of front f is
+ * column Super [f] + k); Rank [f] gets the rank of front f's R block.  Farena
+ * must be zero on entry; on return front f holds R in its first Rank [f] rows. */
+void oracle_multifrontal_tol
+(
+    Long nf, const Long *Post, const Long *Parent, const Long *Super, const Long *Rp,
+    const Long *Fm, const Long *Cm, const Long *Sleft, const Long *Sp,
+    const int *Rjmap, const Long *RjmapOffsets,
+    const int *Rimap, const Long *RimapOffsets, const oracle_sentry *cpuS,
+    const Long *FOffsets, const Long *SOffsets, double *Farena,
+    double tol, char *Rdead, Long *Rank, double *norm_E_fro
+)
+{
+    double wssq = 0 ;
+    for (Long k = 0 ; k < nf ; k++)
+    {
+        Long f = Post [k] ;
+        Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
+        double *F = Farena + FOffsets [f] ;
+        Long Scount = Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]] ;
+        if (Scount > 0) oracle_sassemble (F, cpuS + SOffsets [f], 0, Scount) ;
+        Long rank = oracle_front_qr_tol (F, fm, fn, fp, tol, Rdead + Super [f], &wssq) ;
+        Rank [f] = rank ;
+        Long pid = Parent [f] ;
+        Long cn = fn - fp ;
+        Long cm = fm - rank ;
+        if (cm > cn) cm = cn ;
+        if (cm > Cm [f]) cm = Cm [f] ;      /* cannot happen with a rank-detection analysis */
+        if (pid >= 0 && pid < nf && cm > 0 && cn > 0)
+        {
+            Long pn = Rp [pid+1] - Rp [pid] ;
+            oracle_packassemble (F + rank*fn + fp, fn, cm, cn,
+                Farena + FOffsets [pid], pn, Rimap + RimapOffsets [f], Rjmap + RjmapOffsets [f]) ;
+        }
+    }
+    if (norm_E_fro) *norm_E_fro = sqrt (wssq) ;
+}

@@ -551,12 +551,14 @@ static DeviceCache *device_cache (void)
     DeviceCache *dc = &g_cache [dev] ;
     if (!dc->ready)
     {
-        // the panel stream gets the highest priority: its few long workgroups then take the
-        // compute-unit slots that free up first instead of queueing behind thousands of updates
-        int prio_lo = 0, prio_hi = 0 ;
-        if (hipDeviceGetStreamPriorityRange (&prio_lo, &prio_hi) != hipSuccess) { prio_lo = prio_hi = 0 ; }
-        if (hipStreamCreateWithPriority (&dc->sCompute, hipStreamNonBlocking, prio_hi) != hipSuccess) { dc->release ( ) ; return NULL ; }
-        if (hipStreamCreateWithPriority (&dc->sApply, hipStreamNonBlocking, prio_lo) != hipSuccess) { dc->release ( ) ; return NULL ; }
+        // No stream priorities.  A high-priority panel stream bought under 1 % (its few long workgroups
+        // take the compute-unit slots that free up first), and with several processes on one device it
+        // stalled all of them for good: every launch queued, no stream ever finishing, reproducibly
+        // with three processes holding contexts and gone with equal priorities.  A high-priority queue
+        // parked on a barrier packet that waits for a kernel of the same process's low-priority queue
+        // appears to keep the other processes' low-priority queues from being scheduled.
+        if (hipStreamCreateWithFlags (&dc->sCompute, hipStreamNonBlocking) != hipSuccess) { dc->release ( ) ; return NULL ; }
+        if (hipStreamCreateWithFlags (&dc->sApply, hipStreamNonBlocking) != hipSuccess) { dc->release ( ) ; return NULL ; }
         if (hipStreamCreateWithFlags (&dc->sCopy, hipStreamNonBlocking) != hipSuccess) { dc->release ( ) ; return NULL ; }
         if (hipEventCreate (&dc->evStart) != hipSuccess) { dc->release ( ) ; return NULL ; }
         if (hipEventCreate (&dc->evStop) != hipSuccess) { dc->release ( ) ; return NULL ; }

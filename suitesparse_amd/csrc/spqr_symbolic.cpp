@@ -85,6 +85,15 @@ extern "C" spqr_amd_symbolic *spqr_amd_analyze
     int relax, size_t gpuMemorySize, int *status
 )
 {
+    return spqr_amd_analyze_rd (m, n, Ap, Ai, Quser, relax, gpuMemorySize, 0, status) ;
+}
+
+extern "C" spqr_amd_symbolic *spqr_amd_analyze_rd
+(
+    int64_t m, int64_t n, const int64_t *Ap, const int64_t *Ai, const int64_t *Quser,
+    int relax, size_t gpuMemorySize, int do_rank_detection, int *status
+)
+{
     int dummy ;
     if (!status) status = &dummy ;
     *status = 0 ;
@@ -95,6 +104,7 @@ extern "C" spqr_amd_symbolic *spqr_amd_analyze
         S = new spqr_amd_symbolic ( ) ;
         { static std::atomic<uint64_t> next_uid (1) ; S->uid = next_uid.fetch_add (1) ; }
         S->m = m ; S->n = n ; S->anz = Ap [n] ;
+        S->do_rank_detection = do_rank_detection ? 1 : 0 ;
         const Long anz = Ap [n] ;
 
         // ---- etree of A(:,Quser), postorder, composed permutation ----------------------
@@ -356,7 +366,9 @@ extern "C" spqr_amd_symbolic *spqr_amd_analyze
                 S->Fm [f] = fm ;
                 const Long rm = std::min (fm, fp) ;
                 const Long cn = fn - fp ;
-                S->Cm [f] = std::min (std::max (fm - rm, (Long) 0), cn) ;
+                // with rank detection a front may pass up as many rows as it has (pivot columns can
+                // die and leave their rows to the contribution block): spqr_analyze.cpp:826-842
+                S->Cm [f] = do_rank_detection ? std::min (fm, cn) : std::min (std::max (fm - rm, (Long) 0), cn) ;
                 S->rnz += rm*(rm+1)/2 + rm*(fn-rm) ;
                 S->RjmapOffsets [f] = S->RjmapSize ; S->RjmapSize += cn ;
                 S->RimapOffsets [f] = S->RimapSize ; S->RimapSize += S->Cm [f] ;

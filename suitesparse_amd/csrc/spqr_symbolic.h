@@ -38,6 +38,7 @@ struct spqr_amd_symbolic
     int64_t RimapSize = 0, RjmapSize = 0, numStages = 0, rnz = 0 ;
     double  flopcount = 0 ;
     size_t  gpuMemorySize = 0 ;
+    int     do_rank_detection = 0 ; // Cm and Fm sized for pivot columns that die (spqr_analyze.cpp:826-842)
     uint64_t uid = 0 ;          // unique per analysis in this process (an address can come back, this cannot)
     std::vector<int64_t> Qfill, PLinv, Sleft, Sp, Sj, Super, Rp, Rj, Parent, Childp, Child, Post,
         Fm, Cm, RjmapOffsets, RimapOffsets, Stagingp, StageMap, FSize, RSize, SSize,

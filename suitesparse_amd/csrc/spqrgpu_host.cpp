@@ -10,6 +10,7 @@
 #include <vector>
 #include <algorithm>
 #include <new>
+#include <math.h>
 
 #include "../../include/spqrgpu_amd.h"
 #include "spqr_symbolic.h"
@@ -417,6 +418,39 @@ extern "C" void spqrgpu_amd_finalize (void)
     if (cur >= 0) (void) hipSetDevice (cur) ;
 }
 
+// What a factorization with a tolerance knows after its first pass: which pivot columns are dead.
+// A front with dead columns is factorized again with its columns in the order
+// [live pivot columns | non-pivot columns | dead pivot columns]: the live ones are reduced first, on
+// consecutive rows (which is SPQR's "squeezed" R, spqr_front.cpp:424-479: a dead column does not use
+// up a row), the contribution block sits right behind them, and the dead columns ride along as
+// columns that are updated but whose pivots nobody reads.
+struct RankPlan
+{
+    hostvec<char> dead ;        // size n: pivot column found dead at the tolerance (cumulative over passes)
+    hostvec<char> Rdead ;       // size n: dead, or a live pivot column past the bottom of its front
+    hostvec<char> touched ;     // per front: has dead columns (its columns are permuted)
+    hostvec<Long> live ;        // per front: live pivot columns
+    hostvec<Long> colpos ;      // per front column (at Rp [f] + j): position in the permuted front
+    hostvec<Long> rsize ;       // per front: entries of its squeezed, column-packed R block
+    hostvec<Long> Stair ;       // staircases; full for touched fronts
+    void *d_findex = NULL, *d_Rjmap = NULL ;
+    ~RankPlan ( ) { if (d_findex) (void) hipFree (d_findex) ; if (d_Rjmap) (void) hipFree (d_Rjmap) ; }
+} ;
+
+// Walk the pivot columns of front f in their original order, as spqr_rcount does
+// (SPQR/Source/spqr_rcount.cpp): body (k, rm, is_live) is called with rm = rows of R the column
+// holds (for a live column including its own pivot row).
+template <class Body> static inline void walk_pivots (Long fm, Long fp, Long col1, const char *dead, Body body)
+{
+    Long rm = 0 ;
+    for (Long k = 0 ; k < fp ; k++)
+    {
+        const bool live = !(dead && dead [col1 + k]) && rm < fm ;
+        if (live) rm++ ;
+        body (k, rm, live) ;
+    }
+}
+
 // The numeric factorization of a set of fronts, group by group.  Mirrors
 // spqrgpu_kernel.cpp:63-782: build S and the maps, then per group zero the
 // front arena, ship S, describe the fronts (plus push-only fronts for
@@ -451,7 +485,7 @@ static int factorize_impl
 (
     const spqr_amd_symbolic *S, const int64_t *Ap, const int64_t *Ai, const double *Ax,
     const char *mine, const double *const *limbo_in, const bool limbo_in_dev, double *c_out_dev,
-    double *Rstack_user, int64_t Rstack_room,
+    double *Rstack_user, int64_t Rstack_room, const RankPlan *rp,
     spqr_amd_numeric **num_out
 )
 {
@@ -492,14 +526,23 @@ static int factorize_impl
         // ---- what this call factorizes, and the size of its R ------------------------------
         auto S_count = [&] (Long f) { return std::max ((Long) 0, Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]]) ; } ;
         auto is_mine = [&] (Long f) { return mine == NULL || mine [f] != 0 ; } ;
-        auto c_size = [&] (Long c) { return Cm [c] * ((Rp [c+1] - Rp [c]) - (Super [c+1] - Super [c])) ; } ;
+        // pivot columns a front really has, the rows of its R block, the rows of its contribution block
+        auto npiv_of = [&] (Long f) { return rp ? rp->live [f] : (Super [f+1] - Super [f]) ; } ;
+        auto rank_of = [&] (Long f) { return std::min (Fm [f], npiv_of (f)) ; } ;
+        auto cm_of = [&] (Long f)
+        {
+            const Long cn = (Rp [f+1] - Rp [f]) - (Super [f+1] - Super [f]) ;
+            return std::min (Cm [f], std::min (std::max (Fm [f] - rank_of (f), (Long) 0), cn)) ;
+        } ;
+        auto rsize_of = [&] (Long f) { return rp ? rp->rsize [f] : r_block_size (Rp [f+1] - Rp [f], rank_of (f)) ; } ;
+        auto c_size = [&] (Long c) { return cm_of (c) * ((Rp [c+1] - Rp [c]) - (Super [c+1] - Super [c])) ; } ;
         Long rtotal = 0, ctotal = 0 ;
         for (Long f = 0 ; f < nf ; f++)
         {
             if (!is_mine (f)) continue ;
             const Long fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
-            rtotal += r_block_size (fn, std::min (Fm [f], fp)) ;
-            if (mine && Parent [f] < nf && !mine [Parent [f]]) ctotal += Cm [f] * (fn - fp) ;
+            rtotal += rsize_of (f) ;
+            if (mine && Parent [f] < nf && !mine [Parent [f]]) ctotal += cm_of (f) * (fn - fp) ;
         }
         num->nf = nf ;
         num->rsize = rtotal ;
@@ -594,9 +637,8 @@ static int factorize_impl
             {
                 const Long f = Post [k] ;
                 if (!mine [f]) continue ;
-                const Long fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
                 size_t need = (size_t) (Fm [f] * pitch [f]) * 8 + (size_t) S_count (f) * 16
-                    + (size_t) r_block_size (fn, std::min (Fm [f], fp)) * 8 + (size_t) (((Fm [f] + 31) / 32) * 1024) * 8 ;
+                    + (size_t) rsize_of (f) * 8 + (size_t) (((Fm [f] + 31) / 32) * 1024) * 8 ;
                 size_t kids_here = 0 ;      // blocks of children in the open group: they would have to be copied in
                 for (Long cp = Childp [f] ; cp < Childp [f+1] ; cp++)
                 {
@@ -631,7 +673,6 @@ static int factorize_impl
             {
                 const Long f = list [k] ;
                 if (final_pass) rel [f] = k ;
-                const Long fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
                 if ((pitch [f] & 15) == 0) fsum = (fsum + 15) & ~(Long) 15 ;      // line-aligned rows need a line-aligned base
                 FOff [k] = fsum ; SOff [k] = ssum ; ROff [k] = rsum ;
                 fsum += Fm [f] * pitch [f] ;
@@ -647,7 +688,7 @@ static int factorize_impl
                     fsum += (fsum & 1) ;
                 }
                 ssum += S_count (f) ;
-                rsum += r_block_size (fn, std::min (Fm [f], fp)) ;
+                rsum += rsize_of (f) ;
             }
         } ;
 
@@ -674,12 +715,24 @@ static int factorize_impl
         const bool r_in_engine = num->RstackPinned && getenv ("GPUQR_LATE_R") == NULL ;
         hostvec<PackRTask> ptasks ;
         hostvec<long long> prefix ;
+        hostvec<double> rows_host ;             // unpacked R rows of the group's fronts with dead columns
+        hostvec<Long> rows_at ;
         for (Long g = 0 ; g < ngroups ; g++)
         {
             // ---- fronts of the group, in postorder -----------------------------------------
             layout_group (g, true) ;
             const Long numFronts = (Long) list.size ( ) ;
             if (numFronts == 0) { num->numStagesRun++ ; continue ; }
+            Long rows_off = 0 ;
+            rows_at.assign ((size_t) numFronts, -1) ;
+            if (rp)
+            {
+                Long need = 0 ;
+                for (Long k = 0 ; k < numFronts ; k++)
+                    if (rp->touched [list [k]])     // (the engine also copies the contribution rows of a front whose parent is elsewhere)
+                        need += (rank_of (list [k]) + cm_of (list [k])) * (Rp [list [k]+1] - Rp [list [k]]) ;
+                rows_host.assign ((size_t) std::max ((Long) 1, need), 0.0) ;
+            }
             Buf &dR = (two_r && (g & 1)) ? WS.dR2 : WS.dR ;
             double *F0 = (double *) dF.p ;
             gpuqr_sentry *S0 = (gpuqr_sentry *) dS.p ;
@@ -693,7 +746,7 @@ static int factorize_impl
                 Long k2 = k, cnt = 0 ;
                 while (k2 < numFronts && SGlob [list [k2]] == SGlob [list [k]] + cnt) { cnt += S_count (list [k2]) ; k2++ ; }
                 if (cnt > 0)
-                    HIPCHK (qr_launch_build_s (S0 + SOff [k], (const long long *) NC.d_findex + SGlob [list [k]],
+                    HIPCHK (qr_launch_build_s (S0 + SOff [k], (const long long *) (rp ? rp->d_findex : NC.d_findex) + SGlob [list [k]],
                         (const long long *) NC.d_aperm + SGlob [list [k]], (const double *) dAx.p, cnt, 0)) ;
                 k = k2 ;
             }
@@ -702,20 +755,28 @@ static int factorize_impl
             for (Long k = 0 ; k < numFronts ; k++)
             {
                 const Long f = list [k] ;
-                const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
-                const Long frank = std::min (fm, fp) ;
+                const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = npiv_of (f) ;
+                const Long frank = rank_of (f) ;
                 const Long pid = Parent [f] ;
                 const bool parent_here = in_group (pid, g) ;
+                const int32_t *rjmap_base = (const int32_t *) (rp ? rp->d_Rjmap : NC.d_Rjmap) ;
+                const bool host_packed = rp && rp->touched [f] ;    // R of a front with dead columns is packed by the host
 
                 gpuqr_front &fr = fronts [k] ;
                 memset (&fr, 0, sizeof (fr)) ;
                 fr.fids = k ; fr.pids = parent_here ? rel [pid] : -1 ; fr.fidg = f ; fr.pidg = pid ;
                 fr.fm = fm ; fr.fn = fn ; fr.fp = fp ; fr.rank = frank ;
                 fr.ldn = pitch [f] ;
-                fr.Stair = (int64_t *) Stair.data ( ) + Rp [f] ;
+                fr.Stair = (int64_t *) (rp ? rp->Stair.data ( ) : Stair.data ( )) + Rp [f] ;
                 fr.gpuF = F0 + FOff [k] ;
                 fr.cpuR = NULL ;                    // R is packed on the device, see below
-                if (r_in_engine)
+                if (host_packed)
+                {
+                    fr.cpuR = rows_host.data ( ) + rows_off ;       // the first frank rows, unpacked
+                    rows_at [k] = rows_off ;
+                    rows_off += (frank + cm_of (f)) * fn ;
+                }
+                else if (r_in_engine)
                 {
                     // the engine packs the block once the front is final and sends it while the rest runs
                     fr.gpuRpack = (double *) dR.p + ROff [k] ;
@@ -725,12 +786,12 @@ static int factorize_impl
                 fr.nc = (int32_t) (Childp [f+1] - Childp [f]) ;
                 fr.Scount = S_count (f) ;
                 fr.gpuS = S0 + SOff [k] ;
-                fr.cn = (int32_t) (fn - fp) ;
-                fr.cm = (int32_t) Cm [f] ;
+                fr.cn = (int32_t) ((Rp [f+1] - Rp [f]) - (Super [f+1] - Super [f])) ;
+                fr.cm = (int32_t) cm_of (f) ;
                 if (parent_here)
                 {
                     fr.pn = (int32_t) pitch [pid] ;
-                    fr.gpuRjmap = (int32_t *) NC.d_Rjmap + S->RjmapOffsets [f] ;
+                    fr.gpuRjmap = rjmap_base + S->RjmapOffsets [f] ;
                     fr.gpuRimap = (int32_t *) NC.d_Rimap + S->RimapOffsets [f] ;
                     fr.gpuC = fr.gpuF + frank * pitch [f] + fp ;
                 }
@@ -746,7 +807,7 @@ static int factorize_impl
                     const Long c = Child [cp] ;
                     if (in_group (c, g)) continue ;
                     const Long ccn = (Rp [c+1] - Rp [c]) - (Super [c+1] - Super [c]) ;
-                    const Long ccm = Cm [c] ;
+                    const Long ccm = cm_of (c) ;
                     const bool external = mine && !mine [c] ;
                     gpuqr_front &ch = fronts [next_child] ;
                     memset (&ch, 0, sizeof (ch)) ;
@@ -755,7 +816,7 @@ static int factorize_impl
                     ch.is_sparse = 1 ; ch.push_only = 1 ;
                     ch.pn = (int32_t) pitch [f] ; ch.cm = (int32_t) ccm ; ch.cn = (int32_t) ccn ;
                     ch.gpuRimap = (int32_t *) NC.d_Rimap + S->RimapOffsets [c] ;
-                    ch.gpuRjmap = (int32_t *) NC.d_Rjmap + S->RjmapOffsets [c] ;
+                    ch.gpuRjmap = rjmap_base + S->RjmapOffsets [c] ;
                     const bool in_place = child_in_place (c) ;
                     if (in_place && external)
                     {
@@ -795,7 +856,7 @@ static int factorize_impl
             // One group and nothing arriving from outside it: every call on this symbolic object and
             // these workspaces describes the same problem to the engine, which may then keep its schedule.
             uint64_t plan_key = 0 ;
-            if (ngroups == 1 && nlimbo == 0 && getenv ("GPUQR_NO_PLAN_CACHE") == NULL)
+            if (ngroups == 1 && nlimbo == 0 && !rp && getenv ("GPUQR_NO_PLAN_CACHE") == NULL)
             {
                 const uint64_t parts [7] = {S->uid, (uint64_t) (uintptr_t) dF.p, (uint64_t) (uintptr_t) dS.p,
                     (uint64_t) (uintptr_t) NC.d_Rimap, (uint64_t) (uintptr_t) NC.d_Rjmap, (uint64_t) numFronts,
@@ -829,7 +890,7 @@ static int factorize_impl
                 {
                     const Long f = list [k] ;
                     const Long fn = Rp [f+1] - Rp [f] ;
-                    const Long frank = std::min (Fm [f], Super [f+1] - Super [f]) ;
+                    const Long frank = (rp && rp->touched [f]) ? 0 : rank_of (f) ;
                     PackRTask &pt = ptasks [k] ;
                     pt.F = F0 + FOff [k] ; pt.out = (double *) dR.p + ROff [k] ;
                     pt.ld = (int32_t) pitch [f] ; pt.fn = (int32_t) fn ; pt.frank = (int32_t) frank ; pt.pad = 0 ;
@@ -850,7 +911,7 @@ static int factorize_impl
                     double *dst = num->Rstack + rhead ;
                     const void *src = dR.p ;
                     const size_t bytes = (size_t) rsum * sizeof (double) ;
-                    if (g + 1 < ngroups && getenv ("GPUQR_SERIAL_R") == NULL)
+                    if (g + 1 < ngroups && !rp && getenv ("GPUQR_SERIAL_R") == NULL)
                     {
                         r_thread = std::thread ([&WS, &r_thread_err, dst, src, bytes, wdev] ( )
                         {
@@ -868,11 +929,11 @@ static int factorize_impl
                 {
                     if (!fronts [k].is_staged) continue ;
                     const Long f = list [k] ;
-                    const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = Super [f+1] - Super [f] ;
-                    const Long frank = std::min (fm, fp) ;
-                    const Long cn = fn - fp ;
+                    const Long fn = Rp [f+1] - Rp [f], fp = npiv_of (f) ;
+                    const Long frank = rank_of (f) ;
+                    const Long cn = fn - (Super [f+1] - Super [f]) ;
                     const bool leaves_call = mine && !mine [Parent [f]] ;
-                    const Long cm = leaves_call ? Cm [f] : std::min (fm - frank, cn) ;
+                    const Long cm = cm_of (f) ;
                     const double *Csrc = fronts [k].gpuF + frank * pitch [f] + fp ;
                     double *L ;
                     if (leaves_call && c_out_dev)
@@ -911,6 +972,28 @@ static int factorize_impl
                 }
                 HIPCHK (hipStreamSynchronize (0)) ;
 
+                if (rp)
+                {
+                    // R of the fronts with dead columns: squeezed and column-packed here, from the rows
+                    // the engine copied out, in the original column order (spqr_rhpack's layout)
+                    for (Long k = 0 ; k < numFronts ; k++)
+                    {
+                        const Long f = list [k] ;
+                        if (rows_at [k] < 0) continue ;
+                        const Long fn = Rp [f+1] - Rp [f], fpo = Super [f+1] - Super [f] ;
+                        const double *rows = rows_host.data ( ) + rows_at [k] ;
+                        const Long *pos = rp->colpos.data ( ) + Rp [f] ;
+                        double *out = num->Rstack + num->Rblock [f] ;
+                        Long rm_all = 0 ;
+                        walk_pivots (Fm [f], fpo, Super [f], rp->dead.data ( ), [&] (Long kk, Long rm, bool)
+                        {
+                            for (Long i = 0 ; i < rm ; i++) *out++ = rows [i*fn + pos [kk]] ;
+                            rm_all = rm ;
+                        }) ;
+                        for (Long j = fpo ; j < fn ; j++) for (Long i = 0 ; i < rm_all ; i++) *out++ = rows [i*fn + pos [j]] ;
+                    }
+                }
+
                 for (Long k = 0 ; k < numFronts ; k++)
                 {
                     const Long f = list [k] ;
@@ -931,8 +1014,9 @@ static int factorize_impl
         for (Long f = 0 ; f < nf ; f++)
         {
             const Long fm = Fm [f], fp = Super [f+1] - Super [f] ;
-            const Long frank = std::min (fm, fp) ;
-            for (Long k = fm ; k < fp ; k++) num->Rdead [Super [f] + k] = 1 ;      // pivot columns past the bottom
+            const Long frank = rank_of (f) ;
+            if (rp) { for (Long k = 0 ; k < fp ; k++) num->Rdead [Super [f] + k] = rp->Rdead [Super [f] + k] ; }
+            else for (Long k = fm ; k < fp ; k++) num->Rdead [Super [f] + k] = 1 ;      // pivot columns past the bottom
             if (is_mine (f)) { num->sumfrank += frank ; num->maxfrank = std::max (num->maxfrank, frank) ; }
         }
     }
@@ -960,7 +1044,157 @@ extern "C" int spqrgpu_amd_factorize
 )
 {
     if (!S || !Ap || !Ax || !num_out || (!Ai && S->anz > 0)) return 3 ;
-    return factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, num_out) ;
+    return factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, NULL, num_out) ;
+}
+
+// -----------------------------------------------------------------------------
+// rank detection
+// -----------------------------------------------------------------------------
+
+// SPQR's default tolerance, 20 (m+n) eps max_j ||A(:,j)||_2 (SPQR/Source/spqr_tol.cpp:14-27,
+// spqr_maxcolnorm.cpp).
+extern "C" double spqr_amd_default_tol (int64_t m, int64_t n, const int64_t *Ap, const double *Ax)
+{
+    if (!Ap || (!Ax && n > 0 && Ap [n] > 0)) return -1 ;
+    double maxnorm = 0 ;
+    for (Long j = 0 ; j < n ; j++)
+    {
+        double ss = 0 ;
+        for (Long p = Ap [j] ; p < Ap [j+1] ; p++) ss += Ax [p] * Ax [p] ;
+        maxnorm = std::max (maxnorm, sqrt (ss)) ;
+    }
+    return 20.0 * (double) (m + n) * 2.220446049250313e-16 * maxnorm ;
+}
+
+// Pivot columns of the factorization in `num` whose diagonal entry of R is at or below tol and that
+// are not yet in `dead`: flagged in `dead`, counted in the return value.  The R blocks are
+// column-packed, squeezed by the columns already dead.
+static Long scan_diagonal (const spqr_amd_symbolic *S, const spqr_amd_numeric *num, double tol, char *dead)
+{
+    Long found = 0 ;
+    for (Long f = 0 ; f < S->nf ; f++)
+    {
+        if (num->Rblock [f] < 0) continue ;
+        const double *R = num->Rstack + num->Rblock [f] ;
+        const Long col1 = S->Super [f] ;
+        Long p = 0 ;
+        // (flags raised in this loop belong to the next pass: the walk must see the packing as it is)
+        hostvec<Long> hits ;
+        walk_pivots (S->Fm [f], S->Super [f+1] - col1, col1, dead, [&] (Long k, Long rm, bool live)
+        {
+            p += rm ;
+            if (live && fabs (R [p-1]) <= tol) hits.push_back (col1 + k) ;
+        }) ;
+        for (size_t i = 0 ; i < hits.size ( ) ; i++) { dead [hits [i]] = 1 ; found++ ; }
+    }
+    return found ;
+}
+
+// The plan of a pass that knows the dead columns.  Returns 0, 1 (out of memory), 2 (device).
+static int build_rank_plan (const spqr_amd_symbolic *S, const char *dead, RankPlan &rp)
+{
+    const Long nf = S->nf, n = S->n ;
+    const spqr_amd_symbolic::NumericCache &NC = S->cache ;
+    rp.dead.assign (dead, dead + std::max ((Long) 1, n)) ;
+    rp.Rdead.assign ((size_t) std::max ((Long) 1, n), 0) ;
+    rp.touched.assign ((size_t) std::max ((Long) 1, nf), 0) ;
+    rp.live.assign ((size_t) std::max ((Long) 1, nf), 0) ;
+    rp.rsize.assign ((size_t) std::max ((Long) 1, nf), 0) ;
+    rp.colpos.assign ((size_t) std::max ((Long) 1, S->Rp [nf]), 0) ;
+    rp.Stair.assign (NC.Stair.begin ( ), NC.Stair.end ( )) ;
+    for (Long f = 0 ; f < nf ; f++)
+    {
+        const Long col1 = S->Super [f], fp = S->Super [f+1] - col1, fn = S->Rp [f+1] - S->Rp [f], fm = S->Fm [f] ;
+        Long ndead = 0 ;
+        for (Long k = 0 ; k < fp ; k++) ndead += (dead [col1 + k] != 0) ;
+        const Long L = fp - ndead, cn = fn - fp ;
+        rp.live [f] = L ;
+        rp.touched [f] = (ndead > 0) ;
+        Long *pos = rp.colpos.data ( ) + S->Rp [f] ;
+        Long nl = 0, nd = 0, size = 0, rm_all = 0 ;
+        for (Long k = 0 ; k < fp ; k++) pos [k] = dead [col1 + k] ? (L + cn + nd++) : nl++ ;
+        for (Long j = fp ; j < fn ; j++) pos [j] = L + (j - fp) ;
+        walk_pivots (fm, fp, col1, dead, [&] (Long k, Long rm, bool live)
+        {
+            size += rm ; rm_all = rm ;
+            rp.Rdead [col1 + k] = live ? 0 : 1 ;        // dead at the tolerance, or past the bottom of the front
+        }) ;
+        rp.rsize [f] = size + rm_all * cn ;
+        if (ndead > 0) for (Long j = 0 ; j < fn ; j++) rp.Stair [S->Rp [f] + j] = fm ;   // no staircase to exploit after the permutation
+    }
+    // where the S entries and the children's columns land in the permuted fronts
+    const Long anz = S->anz ;
+    hostvec<Long> findex ((size_t) std::max ((Long) 1, anz)) ;
+    hostvec<int32_t> rjmap (NC.Rjmap.begin ( ), NC.Rjmap.end ( )) ;
+    if (anz > 0 && hipMemcpy (findex.data ( ), NC.d_findex, (size_t) anz * sizeof (Long), hipMemcpyDeviceToHost) != hipSuccess) return 2 ;
+    for (Long f = 0 ; f < nf ; f++)
+    {
+        const Long fn = S->Rp [f+1] - S->Rp [f] ;
+        const Long *pos = rp.colpos.data ( ) + S->Rp [f] ;
+        if (rp.touched [f] && fn > 0)
+            for (Long q = NC.SGlob [f] ; q < NC.SGlob [f] + std::max ((Long) 0, S->Sp [S->Sleft [S->Super [f+1]]] - S->Sp [S->Sleft [S->Super [f]]]) ; q++)
+            {
+                const Long i = findex [q] / fn, j = findex [q] - i * fn ;
+                findex [q] = i * fn + pos [j] ;
+            }
+        const Long pid = S->Parent [f] ;
+        if (pid < nf && rp.touched [pid])
+        {
+            const Long *ppos = rp.colpos.data ( ) + S->Rp [pid] ;
+            int32_t *m = rjmap.data ( ) + S->RjmapOffsets [f] ;
+            for (Long j = 0 ; j < fn - (S->Super [f+1] - S->Super [f]) ; j++) m [j] = (int32_t) ppos [m [j]] ;
+        }
+    }
+    if (hipMalloc (&rp.d_findex, (size_t) std::max ((Long) 1, anz) * sizeof (Long)) != hipSuccess) { rp.d_findex = NULL ; return 1 ; }
+    if (hipMalloc (&rp.d_Rjmap, std::max (rjmap.size ( ), (size_t) 1) * sizeof (int32_t)) != hipSuccess) { rp.d_Rjmap = NULL ; return 1 ; }
+    if (hipMemcpy (rp.d_findex, findex.data ( ), (size_t) anz * sizeof (Long), hipMemcpyHostToDevice) != hipSuccess
+     || hipMemcpy (rp.d_Rjmap, rjmap.data ( ), rjmap.size ( ) * sizeof (int32_t), hipMemcpyHostToDevice) != hipSuccess) return 2 ;
+    return 0 ;
+}
+
+// Numeric factorization with SPQR's rank detection (SPQR/Source/spqr_front.cpp:424-479), which the
+// reference leaves to its CPU path (spqr_analyze.cpp:106-125 turns the GPU off when tol >= 0).  First an
+// ordinary factorization; the pivot columns whose diagonal of R is at or below tol are dead.  If there
+// are any, the fronts are factorized again with the dead columns moved out of the way (RankPlan), which
+// gives SPQR's squeezed R: rank rows, Rdead, dead columns holding the rows above their would-be pivot.
+// A pass that finds further dead columns is repeated with them; the set only grows, three passes at
+// most are expected for clear-cut deficiencies, eight are allowed.  tol < 0: no rank detection.
+extern "C" int spqrgpu_amd_factorize_tol
+(
+    const spqr_amd_symbolic *S, const int64_t *Ap, const int64_t *Ai, const double *Ax, double tol,
+    spqr_amd_numeric **num_out
+)
+{
+    if (!S || !Ap || !Ax || !num_out || (!Ai && S->anz > 0)) return 3 ;
+    if (tol < 0) return factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, NULL, num_out) ;
+    if (!S->do_rank_detection) return 3 ;           // the fronts have no room for rows that dead columns free
+    spqr_amd_numeric *num = NULL ;
+    int code = factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, NULL, &num) ;
+    if (code != 0) return code ;
+    try
+    {
+        hostvec<char> dead ((size_t) std::max ((Long) 1, S->n), 0) ;
+        Long passes = 1 ;
+        while (scan_diagonal (S, num, tol, dead.data ( )) > 0)
+        {
+            if (passes >= 8) { spqr_amd_numeric_free (num) ; return 2 ; }
+            spqr_amd_numeric_free (num) ;
+            num = NULL ;
+            RankPlan rp ;
+            code = build_rank_plan (S, dead.data ( ), rp) ;
+            if (code == 0) code = factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, &rp, &num) ;
+            if (code != 0) return code ;
+            passes++ ;
+        }
+        num->numPasses = passes ;
+    }
+    catch (std::bad_alloc &)
+    {
+        if (num) spqr_amd_numeric_free (num) ;
+        return 1 ;
+    }
+    *num_out = num ;
+    return 0 ;
 }
 
 // What SPQR's numeric phase hands to spqrgpu_kernel and takes back from it, on plain arrays
@@ -980,7 +1214,7 @@ extern "C" int spqrgpu_amd_kernel
 {
     if (!S || (!Sx && S->anz > 0) || (!Stack_head && S->rnz > 0) || !Rblock_offset || !Rdead) return 3 ;
     spqr_amd_numeric *num = NULL ;
-    const int code = factorize_impl (S, NULL, NULL, Sx, NULL, NULL, false, NULL, Stack_head, stack_room, &num) ;
+    const int code = factorize_impl (S, NULL, NULL, Sx, NULL, NULL, false, NULL, Stack_head, stack_room, NULL, &num) ;
     if (code != 0) return code ;
     for (Long f = 0 ; f < S->nf ; f++) Rblock_offset [f] = num->Rblock [f] ;
     for (Long k = 0 ; k < S->n ; k++) if (num->Rdead [k]) Rdead [k] = 1 ;
@@ -1061,7 +1295,7 @@ extern "C" int spqrgpu_amd_factorize_subset
 )
 {
     if (!S || !Ap || !Ax || !mine || !num_out || (!Ai && S->anz > 0)) return 3 ;
-    return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in, false, NULL, NULL, 0, num_out) ;
+    return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in, false, NULL, NULL, 0, NULL, num_out) ;
 }
 
 // The same with the contribution blocks staying on the device on both sides: limbo_in[c] are device
@@ -1076,7 +1310,7 @@ extern "C" int spqrgpu_amd_factorize_subset_dev
 {
     if (!S || !Ap || !Ax || !mine || !num_out || (!Ai && S->anz > 0)) return 3 ;
     if (!c_out_dev && spqrgpu_amd_subset_csize (S, mine) > 0) return 3 ;
-    return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in_dev, true, c_out_dev, NULL, 0, num_out) ;
+    return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in_dev, true, c_out_dev, NULL, 0, NULL, num_out) ;
 }
 
 // Doubles of contribution blocks that leave a subset call: the fronts of the subset whose parent is

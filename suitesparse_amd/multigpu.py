@@ -256,7 +256,7 @@ def gpu_factor_subset_dev(sym, A, mine, limbo, want_R=True):
     return Rblocks, Cblocks, stats
 
 
-def factorize_distributed(sym, A, factor_subset=None, gather_R=True):
+def factorize_distributed(sym, A, factor_subset=None, gather_R=True, trace=None):
     """Factorize A = QR over the ranks of the default torch.distributed group.
 
     Every rank calls this with the same `sym` and `A`.  For L = 0, 1, ...: each rank factorizes its
@@ -266,8 +266,12 @@ def factorize_distributed(sym, A, factor_subset=None, gather_R=True):
     gloo they are staged through host tensors.  `factor_subset` (sym, A, mine, limbo) -> (R, C, stats)
     replaces the GPU driver by a host one working on numpy blocks (the CPU tests pass the oracle).
     With gather_R, rank 0 also collects every R block and returns R (scipy CSC); other ranks return
-    None for it.  Returns (R or None, info dict).
+    None for it.  `trace` (a callable taking a string) is told where the call is, for post-mortems of
+    multi-process runs.  Returns (R or None, info dict).
     """
+    if trace is None:
+        def trace(msg):
+            pass
     import torch
     import torch.distributed as dist
 
@@ -301,6 +305,7 @@ def factorize_distributed(sym, A, factor_subset=None, gather_R=True):
     for L in range(nlev):
         mine = (owner == rank) & (level == L)
         Cout = {}
+        trace("level %d: %d fronts" % (L, int(mine.sum())))
         if mine.any():
             limbo = {}
             for f in np.nonzero(mine)[0]:
@@ -332,6 +337,7 @@ def factorize_distributed(sym, A, factor_subset=None, gather_R=True):
                 landing.append((f, t))
                 if t.numel() > 0:
                     ops.append(dist.P2POp(dist.irecv, t, src))
+        trace("level %d: exchange, %d transfers" % (L, len(ops)))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
@@ -340,6 +346,7 @@ def factorize_distributed(sym, A, factor_subset=None, gather_R=True):
         for f, t in landing:
             held[f] = t.numpy() if host_blocks else t.to(cdev)
 
+    trace("levels done")
     if not gather_R:
         return None, info
 

@@ -27,7 +27,7 @@ class Numeric(C.Structure):
                 ("numStagesRun", C.c_int64), ("assembleBytes", C.c_double),
                 ("Cstack", C.POINTER(C.c_double)), ("Cblock", C.POINTER(C.c_int64)),
                 ("RstackPinned", C.c_int64), ("csize", C.c_int64),
-                ("RstackBorrowed", C.c_int64)]
+                ("RstackBorrowed", C.c_int64), ("numPasses", C.c_int64)]
 
 
 _ARRAYS = ["Qfill", "PLinv", "Sleft", "Sp", "Sj", "Super", "Rp", "Rj", "Parent", "Childp", "Child",
@@ -83,8 +83,10 @@ class Symbolic:
             self._h = None
 
 
-def analyze(A, Q=None, relax=0, gpuMemorySize=0):
-    """spqr_amd_analyze: symbolic analysis + staging of A(:,Q) for the GPU path."""
+def analyze(A, Q=None, relax=0, gpuMemorySize=0, rank_detection=False):
+    """spqr_amd_analyze[_rd]: symbolic analysis + staging of A(:,Q) for the GPU path; with
+    rank_detection the fronts are sized for pivot columns that die at a tolerance
+    (SPQR/Source/spqr_analyze.cpp:826-842), which factorize(..., tol >= 0) needs."""
     L = _bind()
     A = sp.csc_matrix(A)
     A.sort_indices()
@@ -92,11 +94,15 @@ def analyze(A, Q=None, relax=0, gpuMemorySize=0):
     Ap, Ai = _i64(A.indptr), _i64(A.indices)
     Qa = None if Q is None else _i64(Q)
     st = C.c_int(0)
-    h = L.spqr_amd_analyze(m, n, _p(Ap), _p(Ai), _p(Qa), relax, gpuMemorySize, C.byref(st))
+    L.spqr_amd_analyze_rd.restype = C.c_void_p
+    L.spqr_amd_analyze_rd.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_int)]
+    h = L.spqr_amd_analyze_rd(m, n, _p(Ap), _p(Ai), _p(Qa), relax, gpuMemorySize, int(bool(rank_detection)), C.byref(st))
     if not h:
         raise MemoryError("spqr_amd_analyze failed, status %d" % st.value)
     sym = Symbolic(h, st.value)
     sym.gpuMemorySize = gpuMemorySize
+    sym.rank_detection = bool(rank_detection)
     return sym
 
 
@@ -104,9 +110,19 @@ class NumericResult:
     pass
 
 
-def factorize(sym, A, want_R=True):
-    """spqrgpu_amd_factorize (+ spqr_amd_rconvert when want_R): returns R (scipy CSC,
-    sumfrank-by-n) and stats."""
+def default_tol(A):
+    """SPQR_DEFAULT_TOL = 20 (m+n) eps max_j ||A(:,j)||_2 (SPQR/Source/spqr_tol.cpp:14-27)."""
+    L = _bind()
+    A = sp.csc_matrix(A)
+    Ap, Ax = _i64(A.indptr), np.ascontiguousarray(A.data, dtype=np.float64)
+    L.spqr_amd_default_tol.restype = C.c_double
+    L.spqr_amd_default_tol.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    return float(L.spqr_amd_default_tol(A.shape[0], A.shape[1], _p(Ap), _p(Ax)))
+
+
+def factorize(sym, A, want_R=True, tol=None):
+    """spqrgpu_amd_factorize, or spqrgpu_amd_factorize_tol when a tolerance is given
+    (+ spqr_amd_rconvert when want_R): returns R (scipy CSC, rank-by-n) and stats."""
     L = _bind()
     if hasattr(A, "Ap"):                # arrays already in the C ABI's types (multigpu._Csc)
         Ap, Ai, Ax = A.Ap, A.Ai, A.Ax
@@ -115,7 +131,13 @@ def factorize(sym, A, want_R=True):
         A.sort_indices()
         Ap, Ai, Ax = _i64(A.indptr), _i64(A.indices), np.ascontiguousarray(A.data, dtype=np.float64)
     out = C.POINTER(Numeric)()
-    code = L.spqrgpu_amd_factorize(sym._h, _p(Ap), _p(Ai), _p(Ax), C.byref(out))
+    if tol is None:
+        code = L.spqrgpu_amd_factorize(sym._h, _p(Ap), _p(Ai), _p(Ax), C.byref(out))
+    else:
+        L.spqrgpu_amd_factorize_tol.restype = C.c_int
+        L.spqrgpu_amd_factorize_tol.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                                C.POINTER(C.POINTER(Numeric))]
+        code = L.spqrgpu_amd_factorize_tol(sym._h, _p(Ap), _p(Ai), _p(Ax), float(tol), C.byref(out))
     if code != 0:
         raise RuntimeError("spqrgpu_amd_factorize failed with code %d" % code)
     num = out.contents
@@ -136,6 +158,7 @@ def factorize(sym, A, want_R=True):
     res.gpuFlops = int(num.gpuFlops)
     res.gpuNumKernelLaunches = int(num.gpuNumKernelLaunches)
     res.numStagesRun = int(num.numStagesRun)
+    res.numPasses = int(num.numPasses)
     res.assembleBytes = float(num.assembleBytes)
     L.spqr_amd_numeric_free(out)
     return res
@@ -196,6 +219,23 @@ def s_values(sym, A):
     return Sx
 
 
+def append_rhs(A, B, Q=None):
+    """[A B] with B's columns stored structurally dense (explicit zeros kept) and an ordering that
+    puts them last.  A zero of B that was dropped from the pattern could let the column etree's
+    postorder number a column of B before columns of A (a right-hand side supported on one block of
+    a block-diagonal A, say); a dense column is an ancestor of every column, so it stays last, which
+    is where the reference keeps B (SPQR/Source/SuiteSparseQR.cpp:256-260 never orders it)."""
+    A = sp.csc_matrix(A)
+    m, n = A.shape
+    B = np.asarray(B, dtype=np.float64).reshape(m, -1)
+    k = B.shape[1]
+    Bs = sp.csc_matrix((B.ravel(order="F"), np.tile(np.arange(m), k), np.arange(k + 1) * m), shape=(m, k))
+    AB = sp.csc_matrix(sp.hstack([A, Bs], format="csc"))
+    assert AB.nnz == A.nnz + m * k                        # the explicit zeros are still there
+    Qa = np.arange(n) if Q is None else np.asarray(Q)
+    return AB, np.concatenate([Qa, n + np.arange(k)])
+
+
 def qr_solve(A, B, Q=None, relax=0, gpuMemorySize=2**34):
     """min ||A x - B||_2 the way SuiteSparseQR gets Q'B on the GPU path (SuiteSparseQR.cpp:256-260):
     B's columns are appended to A and ride through the same factorization, so that the first n rows
@@ -207,10 +247,11 @@ def qr_solve(A, B, Q=None, relax=0, gpuMemorySize=2**34):
     m, n = A.shape
     B = np.asarray(B, dtype=np.float64).reshape(m, -1)
     k = B.shape[1]
-    AB = sp.hstack([A, sp.csc_matrix(B)], format="csc")
-    Qa = np.arange(n) if Q is None else np.asarray(Q)
-    Qab = np.concatenate([Qa, n + np.arange(k)])          # B's columns stay last, as in SPQR
+    AB, Qab = append_rhs(A, B, Q)
     sym = analyze(AB, Qab, relax=relax, gpuMemorySize=gpuMemorySize)
+    # R(0:n,0:n) is the factor of A(:,Q) only if the analysis kept B's columns behind all of A's
+    if not np.array_equal(np.sort(sym.Qfill[:n]), np.arange(n)):
+        raise RuntimeError("the appended right-hand sides were ordered among A's columns")
     res = factorize(sym, AB)
     R = res.R.tocsc()
     if res.rank < n:

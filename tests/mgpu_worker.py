@@ -62,21 +62,38 @@ def main():
     out_path = sys.argv[2]
     shape = tuple(int(x) for x in sys.argv[3].split("x"))
     rank = int(os.environ["RANK"])
+    t_begin = __import__("time").time()
+
+    def trace(msg):
+        # where this rank is, for the parent test's report when a run hangs
+        path = os.environ.get("MGPU_TRACE")
+        if path:
+            with open("%s.%d" % (path, rank), "a") as f:
+                f.write("%7.2f %s\n" % (__import__("time").time() - t_begin, msg))
+
+    trace("start, mode %s" % mode)
     if mode == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     elif mode == "gloo-gpu":
         torch.cuda.set_device(0)        # all ranks share the one GPU of the test box
+    trace("torch imported, device set")
     dist.init_process_group(backend)
+    trace("process group up")
     A = problems.stacked_ls(shape)
     Q = problems.nested_dissection(shape, leaf=3)
     sym = spqr.analyze(A, Q, relax=0, gpuMemorySize=2**34)
     fs = oracle_factor_subset if mode == "gloo" else None
-    R, info = multigpu.factorize_distributed(sym, A, factor_subset=fs)
+    trace("analysed")
+    R, info = multigpu.factorize_distributed(sym, A, factor_subset=fs, trace=trace)
+    trace("factorized")
     if rank == 0:
         np.savez(out_path, data=R.data, indices=R.indices, indptr=R.indptr, shape=np.array(R.shape),
                  n_cut=info["n_cut"], levels=info["levels"], bound=info["speedup_bound"], Qfill=sym.Qfill)
+    trace("saved")
     dist.barrier()
+    trace("barrier passed")
     dist.destroy_process_group()
+    trace("done")
 
 
 if __name__ == "__main__":

@@ -242,3 +242,89 @@ def test_symbolic_from_arrays_round_trip_and_validation():
         spqr.symbolic_from_arrays(bad, 2**33)
     # (argument validation happens before any device call)
     assert spqr.spqrgpu_kernel(sym2, None)["code"] == 3
+
+
+def test_appended_rhs_with_structured_zeros_stays_last():
+    """Two right-hand sides, each supported on one block of a block-diagonal A: with their zeros
+    dropped, the postorder of the column etree puts a column of B among A's; stored dense they stay
+    last (the reference never orders B's columns, SPQR/Source/SuiteSparseQR.cpp:256-260)."""
+    blk = problems.stacked_ls((4, 4))
+    A = sp.block_diag([blk, blk], format="csc")
+    m, n = A.shape
+    B = np.zeros((m, 2))
+    B[:m // 2, 0] = 1.0
+    B[m // 2:, 1] = 2.0
+    AB, Qab = spqr.append_rhs(A, B)
+    sym = spqr.analyze(AB, Qab, gpuMemorySize=2**32)
+    assert np.array_equal(np.sort(sym.Qfill[:n]), np.arange(n))
+    assert set(sym.Qfill[n:]) == {n, n + 1}
+    # the failure this guards against is real: with the zeros dropped a column of B moves forward
+    ABs = sp.hstack([A, sp.csc_matrix(B)], format="csc")
+    syms = spqr.analyze(ABs, Qab, gpuMemorySize=2**32)
+    assert not np.array_equal(np.sort(syms.Qfill[:n]), np.arange(n))
+
+
+WEST0067 = "/root/reference/UMFPACK/Demo/HB/west0067.rua"
+
+
+@pytest.mark.skipif(not os.path.exists(WEST0067), reason="the reference tree is not on this machine")
+def test_qrdemo_west0067_rank_and_residual():
+    """BASELINE config 1 on the one bundled matrix the reference tree still holds, read in place
+    (never copied): analysis, the oracle's multifrontal QR, least squares through an appended b = ones
+    as SPQR/Demo/qrdemo.cpp:87-105 sets it up, and qrdemo's own check (qrdemo.cpp:22-70):
+    rank 67 and ||Ax-b||_2 / (||A||_1 ||x||_2) at rounding level (the reference built in the survey's
+    scratch directory printed 6.8e-17 for its default ordering)."""
+    import scipy.io
+    A = sp.csc_matrix(scipy.io.hb_read(WEST0067))
+    m, n = A.shape
+    assert (m, n, A.nnz) == (67, 67, 294)
+    b = np.ones((m, 1))
+    AB, Qab = spqr.append_rhs(A, b)
+    sym = spqr.analyze(AB, Qab, gpuMemorySize=2**32)
+    rank = int(sum(min(sym.Fm[f], sym.Super[f + 1] - sym.Super[f]) for f in range(sym.nf)))
+    assert rank == 67
+    Farena, FOff = oracle.multifrontal(sym, spqr.s_values(sym, AB))
+    R = oracle.r_from_fronts(sym, Farena, FOff)
+    assert np.abs(np.diag(R[:n, :n])).min() > 1e-3          # numerically full rank as well
+    x = np.zeros(n)
+    x[sym.Qfill[:n]] = np.linalg.solve(R[:n, :n], R[:n, n])
+    r = A @ x - b[:, 0]
+    rel = np.linalg.norm(r) / (abs(A).sum(axis=0).max() * np.linalg.norm(x))
+    assert rel < 5e-16
+    # R is the factor of A(:,Qfill): unique up to row signs, so LAPACK must agree
+    Rl = np.linalg.qr(A[:, sym.Qfill[:n]].toarray(), mode="r")
+    assert np.abs(np.abs(R[:n, :n]) - np.abs(Rl)).max() <= 1e-12 * np.abs(Rl).max()
+
+
+def test_oracle_rank_detection_against_lapack():
+    """The oracle's restatement of SPQR's dead-column rule (spqr_front.cpp:424-479) on config 5 at a
+    small size: exactly the duplicated and the nearly dependent columns die at SPQR_DEFAULT_TOL, the
+    live columns' part of the squeezed R is LAPACK's R of A(:,live) (unique up to row signs), the dead
+    columns hold Q_live' a_k cut at their would-be pivot row, and R'R = (AQ)'(AQ) to the tolerance."""
+    A, dup, near = problems.rank_deficient_ls(24, 12, 12)
+    Q = problems.nested_dissection((24, 24), leaf=4)
+    sym = spqr.analyze(A, Q, relax=20, gpuMemorySize=2**34, rank_detection=True)
+    n = sym.n
+    tol = spqr.default_tol(A)
+    assert 0 < tol < 1e-9
+    R, Rdead, rank, Rank, enorm = oracle.multifrontal_tol(sym, spqr.s_values(sym, A), tol)
+    assert rank == n - 24 and int(Rdead.sum()) == 24 and enorm < 24 * tol
+    # a dead column is one of each dependent pair (whichever the ordering reaches second)
+    pairs = dup + near
+    inv = np.argsort(sym.Qfill)
+    dead_orig = set(sym.Qfill[np.nonzero(Rdead)[0]].tolist())
+    assert all((a in dead_orig) != (b in dead_orig) for a, b in pairs)
+    R = R.toarray()
+    AQ = A[:, sym.Qfill].toarray()
+    live = np.nonzero(Rdead == 0)[0]
+    Rl = np.linalg.qr(AQ[:, live], mode="r")
+    assert np.abs(np.abs(R[:, live]) - np.abs(Rl)).max() <= 1e-13 * np.abs(Rl).max()
+    G = AQ.T @ AQ
+    assert np.linalg.norm(R.T @ R - G, 1) <= 1e-12 * np.linalg.norm(G, 1)
+    # squeezed: column j of R has nothing below the number of live pivots up to and including it
+    nlive = np.cumsum(Rdead == 0)
+    for j in range(n):
+        assert not R[nlive[j]:, j].any()
+    # without a tolerance nothing dies
+    assert oracle.multifrontal_tol(sym, spqr.s_values(sym, A), -1.0)[2] == n
+    _ = inv

@@ -110,19 +110,31 @@ def test_tree_mapped_ranks_on_one_gpu(tmp_path, world, shape):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "R.npz")
-    port = 29500 + (os.getpid() % 2000)
+    # (a port of its own per case: the store of the previous case may not have let go of its port yet)
+    port = 29500 + (os.getpid() % 2000) + 2000 * (1 + ["20x20", "10x10x10", "9x9x9"].index(shape))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "tests", "mgpu_worker.py"), "gloo-gpu", out, shape]
-    # own process group, so that a hang can be ended together with the workers it left behind
+    # own session, so that a hang can be ended together with the workers it left behind; output to
+    # files, so that nothing blocks on a pipe a surviving grandchild still holds
     import signal
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
-    try:
-        stdout, stderr = proc.communicate(timeout=120)
-    except subprocess.TimeoutExpired:
-        os.killpg(proc.pid, signal.SIGKILL)
-        stdout, stderr = proc.communicate()
-        raise AssertionError("multi-rank run hung:\n" + stdout[-3000:] + stderr[-3000:])
+    trace = str(tmp_path / "trace")
+    with open(str(tmp_path / "out.txt"), "w") as fo:
+        proc = subprocess.Popen(cmd, stdout=fo, stderr=subprocess.STDOUT, start_new_session=True,
+                                env=dict(os.environ, MGPU_TRACE=trace))
+        try:
+            proc.wait(timeout=100)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.wait(timeout=20)
+            report = open(str(tmp_path / "out.txt")).read()[-3000:]
+            for r in range(world):
+                try:
+                    report += "\n-- rank %d --\n%s" % (r, open("%s.%d" % (trace, r)).read())
+                except OSError:
+                    report += "\n-- rank %d: no trace --" % r
+            raise AssertionError("multi-rank run hung:\n" + report)
+    stdout, stderr = open(str(tmp_path / "out.txt")).read(), ""
     assert proc.returncode == 0, stdout[-2000:] + stderr[-2000:]
     z = np.load(out)
     R = sp.csc_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"])).toarray()
@@ -355,3 +367,77 @@ def test_spqr_binding_from_arrays_gives_the_same_r(mem, pageable, monkeypatch):
     assert R.shape == direct.R.shape and (R != direct.R).nnz == 0
     # too little room on the stack is refused
     assert spqr.spqrgpu_kernel(sym2, spqr.s_values(sym, A), stack_room=sym.rnz - 1)["code"] == 1
+
+
+def _rank_case(name):
+    rng = np.random.default_rng(17)
+    if name == "config5-24":
+        A, _, _ = problems.rank_deficient_ls(24, 12, 12)
+        return A, problems.nested_dissection((24, 24), leaf=4), 24
+    if name == "config5-256":
+        A, _, _ = problems.rank_deficient_ls(256, 64, 64)
+        return A, problems.nested_dissection((256, 256), leaf=8), 128
+    if name == "zero-and-duplicate-columns":
+        B = sp.random(160, 60, density=0.08, random_state=3, format="lil")
+        B[:60, :] += sp.identity(60)
+        B[:, 7] = 0                                 # a column of zeros
+        B[:, 20] = B[:, 19]                         # neighbours in the ordering
+        B[:, 41] = 2.5 * B[:, 3]                    # far apart
+        B[:, 59] = B[:, 58]                         # the last column
+        return sp.csc_matrix(B), None, 4
+    if name == "wide":
+        # more columns than rows: pivot columns run out of rows, and two die before that
+        B = sp.random(30, 45, density=0.3, random_state=5, format="lil")
+        B[:, 4] = B[:, 2]
+        B[:, 5] = -B[:, 2]
+        return sp.csc_matrix(B), rng.permutation(45), None
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["config5-24", "zero-and-duplicate-columns", "wide", "config5-256"])
+def test_rank_detection_on_the_device_matches_the_cpu_rule(name):
+    """Config 5: rank-deficient least squares at SPQR's default tolerance.  The device path
+    (spqrgpu_amd_factorize_tol) must give the CPU rule's answer (the oracle restates
+    SPQR/Source/spqr_front.cpp:424-479): the same dead columns, the same rank, the same squeezed R
+    (pattern: one row per live pivot, dead columns cut at their would-be pivot row; values to 1e-12),
+    and R'R = (AQ)'(AQ) to the tolerance."""
+    A, Q, expect_dead = _rank_case(name)
+    A = sp.csc_matrix(A)
+    m, n = A.shape
+    sym = spqr.analyze(A, Q, relax=20, gpuMemorySize=2**36, rank_detection=True)
+    tol = spqr.default_tol(A)
+    res = spqr.factorize(sym, A, tol=tol)
+    Ro, Rdead_o, rank_o, _, _ = oracle.multifrontal_tol(sym, spqr.s_values(sym, A), tol)
+    assert res.rank == rank_o
+    assert np.array_equal(res.Rdead, Rdead_o)
+    if expect_dead is not None:
+        assert int(res.Rdead.sum()) == expect_dead + max(0, n - m) * 0 and res.rank == n - int(res.Rdead.sum())
+        assert res.numPasses >= 2
+    R = res.R.tocsc()
+    assert R.shape == Ro.shape == (rank_o, n)
+    # same pattern (structural: explicit zeros count) ...
+    R.sort_indices()
+    Ro.sort_indices()
+    assert np.array_equal(R.indptr, Ro.indptr) and np.array_equal(R.indices, Ro.indices)
+    # ... and the same numbers up to the sign of a row
+    scale = np.abs(Ro.data).max()
+    assert np.abs(np.abs(R.data) - np.abs(Ro.data)).max() <= 1e-12 * scale
+    # R'R = (AQ)'(AQ) up to what the dead columns dropped
+    AQ = A[:, sym.Qfill]
+    G = (AQ.T @ AQ)
+    E = (R.T @ R - G)
+    assert abs(E).sum(axis=0).max() <= 10 * tol * abs(G).sum(axis=0).max() ** 0.5 + 1e-12 * abs(G).sum(axis=0).max()
+
+
+def test_rank_detection_needs_its_analysis_and_costs_nothing_at_full_rank():
+    A = problems.stacked_ls((20, 20))
+    Q = problems.nested_dissection((20, 20), leaf=4)
+    plain = spqr.analyze(A, Q, gpuMemorySize=2**34)
+    with pytest.raises(RuntimeError):
+        spqr.factorize(plain, A, tol=1e-10)              # fronts not sized for dying columns: refused (3)
+    sym = spqr.analyze(A, Q, gpuMemorySize=2**34, rank_detection=True)
+    res = spqr.factorize(sym, A, tol=spqr.default_tol(A))
+    ref = spqr.factorize(plain, A)
+    assert res.numPasses == 1 and res.rank == sym.n and res.Rdead.sum() == 0
+    assert np.abs(res.R - ref.R).max() <= 1e-13 * np.abs(ref.R).max()
+    assert (spqr.factorize(sym, A, tol=-1.0).R != spqr.factorize(sym, A).R).nnz == 0
