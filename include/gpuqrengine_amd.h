@@ -74,6 +74,12 @@ typedef struct gpuqr_front
      * one transfer.  Both NULL: nothing happens. */
     double *gpuRpack;
     double *cpuRpack;
+    /* Right-hand-side block, no counterpart in the reference's Front (its GPU path gets Q'B only by
+     * appending B to A before the analysis, SPQR/Source/SuiteSparseQR.cpp:256-260): columns
+     * [rhs_col, rhs_col + rhs_n) of the front's storage, rhs_col >= fn and rhs_col + rhs_n <= ldn.
+     * Every panel's block reflector is applied to them; they are never factorized.  rhs_n = 0: none. */
+    int32_t rhs_col;
+    int32_t rhs_n;
 } gpuqr_front;
 
 /* same fields as QREngineStats (GPUQREngine/Include/GPUQREngine_Stats.hpp:13-29) */
@@ -131,6 +137,21 @@ size_t gpuqr_max_queue_size (size_t gpuMemorySize);
 int gpuqr_factor_sparse_keyed (size_t gpuMemorySize, gpuqr_front *fronts, int64_t numFronts,
                                const int64_t *Parent, const int64_t *Childp, const int64_t *Child,
                                gpuqr_stats *stats, uint64_t plan_key);
+
+/* gpuqr_factor_sparse that keeps H: the block reflectors stay usable after the call (V in place in
+ * the fronts, the VT tiles in memory the returned object owns), and the update tasks of the fronts'
+ * right-hand-side blocks (gpuqr_front.rhs_col / rhs_n) can be run again on new contents of those
+ * blocks: gpuqr_replay_round (rp, r, stream) queues round r of them, r = 0 .. gpuqr_replay_rounds - 1;
+ * gpuqr_replay_front_done (rp, f) is the last round that touches front f (its finished rows may be
+ * handed to the parent's block after it).  What the reference would need keepH for and therefore
+ * leaves to the CPU (SPQR/Source/SuiteSparseQR_expert.cpp:324-343).  The fronts must stay in place,
+ * unmodified, while the object lives.  One stream, rounds in order. */
+typedef struct gpuqr_replay gpuqr_replay;
+int gpuqr_factor_sparse_keep (gpuqr_front *fronts, int64_t numFronts, gpuqr_stats *stats, gpuqr_replay **out);
+int32_t gpuqr_replay_rounds (const gpuqr_replay *rp);
+int32_t gpuqr_replay_front_done (const gpuqr_replay *rp, int64_t front);
+int gpuqr_replay_round (const gpuqr_replay *rp, int32_t round, void *hip_stream);
+void gpuqr_replay_free (gpuqr_replay *rp);
 
 /* Exact flop count of the schedule the engine would run for one fm-by-fn
  * front with staircase Stair (NULL = full), the analogue of getFlops

@@ -160,6 +160,28 @@ int spqrgpu_amd_factorize_tol (const spqr_amd_symbolic *sym, const int64_t *Ap, 
                                const double *Ax, double tol, spqr_amd_numeric **num_out);
 double spqr_amd_default_tol (int64_t m, int64_t n, const int64_t *Ap, const double *Ax);
 
+/* --- H kept on the device: Q'B and solves after the factorization ---------------------------------
+ *
+ * The reference gets Q'B on its GPU path only by appending B to A before the analysis
+ * (SPQR/Source/SuiteSparseQR.cpp:256-260); anything that needs H later (SuiteSparseQR_qmult,
+ * SuiteSparseQR_solve on a factorization object, SPQR/Source/SuiteSparseQR_expert.cpp:324-343) forces
+ * keepH and with it the CPU.  spqrgpu_amd_factorize_keep is spqrgpu_amd_factorize that leaves H where
+ * the factorization made it: the fronts (Householder vectors in place) stay in a device arena the
+ * returned object owns, with a block of nrhs (1..256) right-hand-side columns behind every front, and
+ * the engine keeps the VT tiles and the update tasks of those blocks.  spqrgpu_amd_qtmult then
+ * computes, for any B (m-by-nrhs, column-major, leading dimension ldb), the first rank rows of Q'B in
+ * the row order of R (C, rank-by-nrhs, leading dimension ldc; rank = spqr_amd_qt_rank): exactly what
+ * R x = Q'B needs.  One factorization, any number of right-hand sides.  Single-stage factorizations
+ * only (the fronts must all be resident); the symbolic object must not be a rank-detection one.
+ * Return codes as spqrgpu_amd_factorize. */
+typedef struct spqr_amd_qt spqr_amd_qt;
+int spqrgpu_amd_factorize_keep (const spqr_amd_symbolic *sym, const int64_t *Ap, const int64_t *Ai,
+                                const double *Ax, int64_t nrhs,
+                                spqr_amd_numeric **num_out, spqr_amd_qt **qt_out);
+int spqrgpu_amd_qtmult (spqr_amd_qt *qt, const double *B, int64_t ldb, double *C, int64_t ldc);
+int64_t spqr_amd_qt_rank (const spqr_amd_qt *qt);
+void spqr_amd_qt_free (spqr_amd_qt *qt);
+
 /* The body of void spqrgpu_kernel (spqr_blob <double> *Blob) on plain arrays
  * (SPQR/Include/spqrgpu.hpp:9-14, SPQR/SPQRGPU/spqrgpu_kernel.cpp:63-782; adapter/spqrgpu_kernel.cpp
  * is the translation unit with the reference's signature that calls it).  Sx = Blob->Sx, the values

@@ -29,6 +29,7 @@ class FrontC(C.Structure):
         ("cm", C.c_int32), ("cn", C.c_int32), ("pn", C.c_int32), ("pad1", C.c_int32),
         ("gpuRjmap", C.c_void_p), ("gpuRimap", C.c_void_p), ("gpuC", C.c_void_p),
         ("gpuRpack", C.c_void_p), ("cpuRpack", C.c_void_p),
+        ("rhs_col", C.c_int32), ("rhs_n", C.c_int32),
     ]
 
 

@@ -186,6 +186,7 @@ struct SchedTask
     int32_t nblk ;      // workgroups this task is run by (apply: column blocks; else 1)
     int32_t wait_ctr ;  // work queue: counter (= front) whose earlier rounds this task waits for
     int32_t signal_ctr ;// work queue: counter this task reports to (the parent's, for pack assembly)
+    int32_t is_rhs ;    // update task whose columns are the front's right-hand-side block (kept for Q'B replays)
     double  flops ;     // algorithmic flops of this task
     double  bytes ;     // algorithmic (minimum) bytes it moves to and from memory
 } ;
@@ -280,16 +281,20 @@ static int lookahead_min_tiles (void)
 static void plan_front
 (
     Plan &plan, double *F, int64_t fm, int64_t fn, int64_t ld, const int64_t *Stair,
-    int32_t last [QR_NCLASS], bool emit
+    int32_t last [QR_NCLASS], bool emit, int64_t rhs_col = 0, int64_t rhs_n = 0
 )
 {
     if (fm <= 0 || fn <= 0) return ;
     const int64_t mn = (fm < fn) ? fm : fn ;
     const int64_t npanels = (mn + QR_PANEL_W - 1) / QR_PANEL_W ;
     const int64_t ntiles  = (fn + QR_PANEL_W - 1) / QR_PANEL_W ;
+    // Right-hand-side columns [rhs_col, rhs_col + rhs_n) of the front's storage (beyond its fn columns):
+    // every panel's reflectors are applied to them, none of them is ever factorized.  They are
+    // tracked as one more column tile.
+    const bool has_rhs = (rhs_n > 0) ;
     // latest round of each class that wrote column tile t
     hvec<int32_t> lastw [QR_NCLASS] ;
-    for (int c = 0 ; c < QR_NCLASS ; c++) lastw [c].assign ((size_t) ntiles, last [c]) ;
+    for (int c = 0 ; c < QR_NCLASS ; c++) lastw [c].assign ((size_t) ntiles + 1, last [c]) ;
     hvec<Seg> tops, next ;
     int64_t e_prev = 0 ;
     const int la_min = lookahead_min_tiles ( ) ;
@@ -312,6 +317,7 @@ static void plan_front
         e_prev = e ;
         const int64_t m = e - r0 ;
         const bool trailing = (c0 + w < fn) ;
+        const bool wants_vt = trailing || has_rhs ;
 
         // ---- factorize tasks, level by level ---------------------------------
         struct FRef { int64_t vt ; int32_t K ; int32_t nseg ; Seg segs [QR_MAX_SEG] ; int32_t level ; } ;
@@ -329,7 +335,7 @@ static void plan_front
             int64_t b = (a + QR_MAX_K < e) ? (a + QR_MAX_K) : e ;
             fr.K = (int32_t) (b - a) ; fr.nseg = 1 ; fr.level = 0 ;
             fr.segs [0].row = (int32_t) a ; fr.segs [0].n = fr.K ;
-            fr.vt = trailing ? plan.n_vt++ : -1 ;
+            fr.vt = wants_vt ? plan.n_vt++ : -1 ;
             frefs.push_back (fr) ;
             Seg s ; s.row = (int32_t) a ; s.n = (int32_t) ((fr.K < w) ? fr.K : w) ;
             tops.push_back (s) ;
@@ -344,7 +350,7 @@ static void plan_front
                 if (gend - g == 1) { next.push_back (tops [g]) ; continue ; }
                 FRef fr ; fr.nseg = (int32_t) (gend - g) ; fr.K = 0 ; fr.level = level ;
                 for (size_t s = g ; s < gend ; s++) { fr.segs [s-g] = tops [s] ; fr.K += tops [s].n ; }
-                fr.vt = trailing ? plan.n_vt++ : -1 ;
+                fr.vt = wants_vt ? plan.n_vt++ : -1 ;
                 frefs.push_back (fr) ;
                 Seg s = tops [g] ; s.n = (int32_t) ((fr.K < w) ? fr.K : w) ;
                 next.push_back (s) ;
@@ -356,7 +362,7 @@ static void plan_front
         for (size_t i = 0 ; i < frefs.size ( ) ; i++)
         {
             const FRef &fr = frefs [i] ;
-            plan.flops += flops_factorize (fr.K, w, trailing) ;
+            plan.flops += flops_factorize (fr.K, w, wants_vt) ;
             if (!emit) continue ;
             SchedTask st ;
             memset (&st, 0, sizeof (st)) ;
@@ -372,8 +378,8 @@ static void plan_front
             if (fr.level > 0) st.dep [0] = rF0 + fr.level - 1 ;
             st.vt = fr.vt ;
             st.nblk = 1 ;
-            st.flops = (double) flops_factorize (fr.K, w, trailing) ;
-            st.bytes = 16.0 * fr.K * w + (trailing ? 8.0 * QR_VT_DOUBLES : 0.0) ;
+            st.flops = (double) flops_factorize (fr.K, w, wants_vt) ;
+            st.bytes = 16.0 * fr.K * w + (wants_vt ? 8.0 * QR_VT_DOUBLES : 0.0) ;
             plan.tasks.push_back (st) ;
         }
         lastw [0][p] = rF0 + nlevels - 1 ;
@@ -441,6 +447,53 @@ static void plan_front
                         for (int64_t t = ta ; t < tb ; t++) lastw [c][t] = used [c] ;
                         last [c] = std::max (last [c], used [c]) ;
                     }
+                }
+            }
+        }
+        // ---- the same reflectors on the right-hand-side block ----------------------------
+        if (has_rhs)
+        {
+            const int64_t tr = ntiles ;         // the tile that stands for the block
+            for (int32_t lv = 0 ; lv < nlevels ; lv++)
+            {
+                int32_t dep [QR_NCLASS] ;
+                for (int c = 0 ; c < QR_NCLASS ; c++) dep [c] = lastw [c][tr] ;
+                dep [0] = std::max (dep [0], rF0 + lv) ;
+                const int32_t round = 1 + std::max (dep [0], std::max (dep [1], dep [2])) ;
+                int32_t used [QR_NCLASS] = {-1, -1, -1} ;
+                for (size_t i = 0 ; i < frefs.size ( ) ; i++)
+                {
+                    const FRef &fr = frefs [i] ;
+                    if (fr.level != lv) continue ;
+                    plan.flops += flops_apply (fr.K, w, rhs_n) ;
+                    const int tier = tier_of (fr.K) ;
+                    const int slot = 4 + tier ;
+                    used [slot_class (slot)] = round ;
+                    if (!emit) continue ;
+                    SchedTask st ;
+                    memset (&st, 0, sizeof (st)) ;
+                    st.t.type = QR_TASK_APPLY ;
+                    st.t.tier = tier ;
+                    QrPanelTask &pt = st.t.u.panel ;
+                    pt.F = F ; pt.VT = NULL ; pt.ld = (int32_t) ld ; pt.col0 = (int32_t) c0 ; pt.w = (int32_t) w ;
+                    pt.K = fr.K ; pt.nseg = fr.nseg ; pt.c_begin = (int32_t) rhs_col ; pt.c_end = (int32_t) (rhs_col + rhs_n) ;
+                    pt.cb_cols = (int32_t) ((rhs_n + 15) / 16 * 16) ;
+                    for (int s = 0 ; s < fr.nseg ; s++) { pt.seg_row [s] = fr.segs [s].row ; pt.seg_n [s] = fr.segs [s].n ; }
+                    st.round = round ;
+                    st.slot = slot ;
+                    for (int c = 0 ; c < QR_NCLASS ; c++) st.dep [c] = dep [c] ;
+                    st.vt = fr.vt ;
+                    st.nblk = 1 ;
+                    st.is_rhs = 1 ;
+                    st.flops = (double) flops_apply (fr.K, w, rhs_n) ;
+                    st.bytes = 16.0 * fr.K * (double) rhs_n + 8.0 * fr.K * w + 8.0 * QR_VT_DOUBLES ;
+                    plan.tasks.push_back (st) ;
+                }
+                for (int c = 0 ; c < QR_NCLASS ; c++)
+                {
+                    if (used [c] < 0) continue ;
+                    lastw [c][tr] = used [c] ;
+                    last [c] = std::max (last [c], used [c]) ;
                 }
             }
         }
@@ -1043,6 +1096,8 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
             if (fr.fm < 0 || fr.fn < 0 || fr.fm > INT32_MAX || fr.fn > INT32_MAX) return GPUQR_GPUERROR ;
             if (fr.fm > 0 && fr.fn > 0 && fr.gpuF == NULL) return GPUQR_GPUERROR ;
             if (front_pitch (fr) > INT32_MAX) return GPUQR_GPUERROR ;
+            if (fr.rhs_n < 0 || (fr.rhs_n > 0 && (fr.rhs_n > 256 || fr.rhs_col < fr.fn || fr.rhs_col + fr.rhs_n > front_pitch (fr))))
+                return GPUQR_GPUERROR ;
             if (fr.is_sparse && fr.pids >= 0 && fr.cm > 0 && fr.cn > 0)
             {
                 if (!fr.gpuRimap || !fr.gpuRjmap || !fr.gpuC) return GPUQR_GPUERROR ;
@@ -1102,7 +1157,7 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
                     }
                     if (fr.Scount > 0) last [2] = std::max (last [2], 0) ;
                 }
-                plan_front (plan, fr.gpuF, fr.fm, fr.fn, front_pitch (fr), fr.Stair, last, true) ;
+                plan_front (plan, fr.gpuF, fr.fm, fr.fn, front_pitch (fr), fr.Stair, last, true, fr.rhs_col, fr.rhs_n) ;
             }
             for (int c = 0 ; c < QR_NCLASS ; c++) done_last [f*QR_NCLASS + c] = last [c] ;
             for (size_t i = first_task ; i < plan.tasks.size ( ) ; i++)
@@ -1165,7 +1220,7 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
             for (int64_t i = 0 ; i < ntasks ; i++)
             {
                 SchedTask &st = plan.tasks [i] ;
-                if (st.t.type != QR_TASK_APPLY) continue ;
+                if (st.t.type != QR_TASK_APPLY || st.is_rhs) continue ;
                 QrPanelTask &pt = st.t.u.panel ;
                 int64_t tot = total [(int64_t) st.round * QR_NSLOTS + st.slot] ;
                 const int32_t width = pt.c_end - pt.c_begin ;
@@ -1635,6 +1690,148 @@ cleanup:
 // -----------------------------------------------------------------------------
 // dense overload: host fronts in, R out
 // -----------------------------------------------------------------------------
+
+// -----------------------------------------------------------------------------
+// factorization that keeps H, and replays of it on new right-hand sides
+// -----------------------------------------------------------------------------
+
+// What a kept factorization owns: the VT tiles (the fronts themselves, with V in place, belong to the
+// caller), the update tasks of the right-hand-side blocks in launch order, and when each front is done.
+struct gpuqr_replay
+{
+    void *d_vt = NULL, *d_tasks = NULL, *d_refs = NULL ;
+    hvec<int64_t> rptr ;            // first workgroup of every (round, slot) bucket of the replay
+    hvec<int32_t> done_round ;      // per front: last round in which the factorization touched it
+    int32_t nrounds = 0 ;
+    int64_t nrefs = 0 ;
+    int device = -1 ;
+} ;
+
+extern "C" void gpuqr_replay_free (gpuqr_replay *rp)
+{
+    if (!rp) return ;
+    if (rp->d_vt) (void) hipFree (rp->d_vt) ;
+    if (rp->d_tasks) (void) hipFree (rp->d_tasks) ;
+    if (rp->d_refs) (void) hipFree (rp->d_refs) ;
+    rp->~gpuqr_replay ( ) ;
+    g_free (rp) ;
+}
+
+extern "C" int32_t gpuqr_replay_rounds (const gpuqr_replay *rp) { return rp ? rp->nrounds : 0 ; }
+extern "C" int32_t gpuqr_replay_front_done (const gpuqr_replay *rp, int64_t f)
+{
+    return (rp && f >= 0 && f < (int64_t) rp->done_round.size ( )) ? rp->done_round [f] : -1 ;
+}
+
+// The updates of round r on the right-hand-side blocks, queued on `stream` (no waiting).
+extern "C" int gpuqr_replay_round (const gpuqr_replay *rp, int32_t r, void *hip_stream)
+{
+    hipStream_t stream = (hipStream_t) hip_stream ;
+    if (!rp || r < 0 || r >= rp->nrounds) return GPUQR_GPUERROR ;
+    for (int slot = 0 ; slot < QR_NSLOTS ; slot++)
+    {
+        const int64_t b = (int64_t) r * QR_NSLOTS + slot ;
+        const int64_t n = rp->rptr [b+1] - rp->rptr [b] ;
+        if (n <= 0) continue ;
+        if (qr_launch_tasks (slot_kernel (slot), (const QrTask *) rp->d_tasks, (const QrRef *) rp->d_refs + rp->rptr [b],
+            (int) n, stream) != hipSuccess) return GPUQR_GPUERROR ;
+    }
+    return GPUQR_SUCCESS ;
+}
+
+// gpuqr_factor_sparse that keeps the Householder vectors usable afterwards.  The fronts carry a
+// right-hand-side block (gpuqr_front.rhs_col / rhs_n: columns of the front's storage beyond its fn
+// columns, zero or holding a right-hand side already): every panel's block reflector is applied to
+// that block too, its VT tile goes to memory the returned object owns, and the update tasks of the
+// blocks are kept on the device so that gpuqr_replay_round can push new right-hand sides through the
+// same reflectors, round by round, once the caller has put their rows in place.  The fronts must
+// stay where they are, untouched, while the object lives.  One stream, rounds in order.
+extern "C" int gpuqr_factor_sparse_keep (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, gpuqr_replay **out)
+{
+    if (out) *out = NULL ;
+    if (stats) { stats->kernelTime = 0 ; stats->numLaunches = 0 ; stats->flopsActual = 0 ; }
+    if (!out || nf < 0 || (nf > 0 && fronts == NULL)) return GPUQR_GPUERROR ;
+    DeviceCache *dc = device_cache ( ) ;
+    if (!dc) return GPUQR_GPUERROR ;
+    int code = GPUQR_SUCCESS ;
+    hipStream_t stream = dc->sCompute ;
+    bool eng_verbose = false ; double eng_tlast = 0 ;
+    gpuqr_replay *rp = (gpuqr_replay *) g_calloc (1, sizeof (gpuqr_replay)) ;
+    if (!rp) return GPUQR_OUTOFMEMORY ;
+    new (rp) gpuqr_replay ( ) ;
+    (void) hipGetDevice (&rp->device) ;
+    try
+    {
+        Schedule sc ;
+        code = build_schedule (fronts, nf, sc, eng_verbose, eng_tlast) ;
+        if (code != GPUQR_SUCCESS) { gpuqr_replay_free (rp) ; return code ; }
+        const size_t task_bytes = (size_t) std::max<int64_t> (sc.ntasks, 1) * sizeof (QrTask) ;
+        const size_t ref_bytes = (size_t) std::max<int64_t> (sc.nrefs, 1) * sizeof (QrRef) ;
+        const size_t vt_bytes = (size_t) std::max<int64_t> (sc.plan.n_vt, 1) * QR_VT_DOUBLES * sizeof (double) ;
+        void *d_refs_all = NULL ;
+        if (hipMalloc (&rp->d_vt, vt_bytes) != hipSuccess) { rp->d_vt = NULL ; gpuqr_replay_free (rp) ; return GPUQR_OUTOFMEMORY ; }
+        if (hipMalloc (&rp->d_tasks, task_bytes) != hipSuccess) { rp->d_tasks = NULL ; gpuqr_replay_free (rp) ; return GPUQR_OUTOFMEMORY ; }
+        if (hipMalloc (&d_refs_all, ref_bytes) != hipSuccess) { gpuqr_replay_free (rp) ; return GPUQR_OUTOFMEMORY ; }
+        hvec<QrTask> h_tasks ((size_t) std::max<int64_t> (sc.ntasks, 1)) ;
+        hvec<QrRef> h_refs ((size_t) std::max<int64_t> (sc.nrefs, 1)) ;
+        code = stage_tasks (sc, (double *) rp->d_vt, h_tasks.data ( ), h_refs.data ( )) ;
+        // the replay: the right-hand-side updates alone, in the same (round, slot) buckets
+        rp->nrounds = sc.nrounds ;
+        rp->rptr.assign ((size_t) sc.nbuckets + 1, 0) ;
+        hvec<QrRef> r_refs ;
+        if (code == GPUQR_SUCCESS)
+        {
+            for (int64_t i = 0 ; i < sc.ntasks ; i++)
+                if (sc.plan.tasks [i].is_rhs) rp->rptr [(int64_t) sc.plan.tasks [i].round * QR_NSLOTS + sc.plan.tasks [i].slot + 1]++ ;
+            for (int64_t b = 0 ; b < sc.nbuckets ; b++) rp->rptr [b+1] += rp->rptr [b] ;
+            rp->nrefs = rp->rptr [sc.nbuckets] ;
+            r_refs.assign ((size_t) std::max<int64_t> (rp->nrefs, 1), QrRef ( )) ;
+            hvec<int64_t> pos (rp->rptr) ;
+            for (int64_t i = 0 ; i < sc.ntasks ; i++)
+            {
+                const SchedTask &st = sc.plan.tasks [i] ;
+                if (!st.is_rhs) continue ;
+                QrRef &q = r_refs [pos [(int64_t) st.round * QR_NSLOTS + st.slot]++] ;
+                q.task = (int32_t) i ; q.blk = 0 ;
+            }
+            rp->done_round.assign ((size_t) nf, -1) ;
+            for (int64_t f = 0 ; f < nf ; f++)
+                rp->done_round [f] = std::max (sc.done_last [f*QR_NCLASS], std::max (sc.done_last [f*QR_NCLASS+1], sc.done_last [f*QR_NCLASS+2])) ;
+            if (hipMalloc (&rp->d_refs, r_refs.size ( ) * sizeof (QrRef)) != hipSuccess) { rp->d_refs = NULL ; code = GPUQR_OUTOFMEMORY ; }
+        }
+        if (code == GPUQR_SUCCESS)
+        {
+            int64_t launches = 0 ;
+            float ms = 0 ;
+            bool ok = hipMemcpyAsync (rp->d_tasks, h_tasks.data ( ), (size_t) sc.ntasks * sizeof (QrTask), hipMemcpyHostToDevice, stream) == hipSuccess
+                && hipMemcpyAsync (d_refs_all, h_refs.data ( ), (size_t) sc.nrefs * sizeof (QrRef), hipMemcpyHostToDevice, stream) == hipSuccess
+                && hipMemcpyAsync (rp->d_refs, r_refs.data ( ), r_refs.size ( ) * sizeof (QrRef), hipMemcpyHostToDevice, stream) == hipSuccess
+                && hipEventRecord (dc->evStart, stream) == hipSuccess ;
+            for (int32_t r = 0 ; ok && r < sc.nrounds ; r++)
+                for (int slot = 0 ; ok && slot < QR_NSLOTS ; slot++)
+                {
+                    const int64_t b = (int64_t) r * QR_NSLOTS + slot ;
+                    const int64_t n = sc.rptr [b+1] - sc.rptr [b] ;
+                    if (n <= 0) continue ;
+                    ok = qr_launch_tasks (slot_kernel (slot), (const QrTask *) rp->d_tasks, (const QrRef *) d_refs_all + sc.rptr [b], (int) n, stream) == hipSuccess ;
+                    launches++ ;
+                }
+            ok = ok && hipEventRecord (dc->evStop, stream) == hipSuccess ;
+            ok = (hipStreamSynchronize (stream) == hipSuccess) && ok ;
+            if (ok) ok = hipEventElapsedTime (&ms, dc->evStart, dc->evStop) == hipSuccess ;
+            if (!ok) code = GPUQR_GPUERROR ;
+            if (stats) { stats->kernelTime = ms ; stats->numLaunches = launches ; stats->flopsActual = sc.plan.flops ; }
+        }
+        (void) hipFree (d_refs_all) ;
+    }
+    catch (std::bad_alloc &)
+    {
+        code = GPUQR_OUTOFMEMORY ;
+    }
+    if (code != GPUQR_SUCCESS) { (void) hipStreamSynchronize (stream) ; gpuqr_replay_free (rp) ; return code ; }
+    *out = rp ;
+    return GPUQR_SUCCESS ;
+}
 
 // Row pitch of the device copy of a dense front: even, so that with a 16-byte aligned base every
 // row starts on a 16-byte boundary (the update kernel moves two columns per lane); from 96 columns

@@ -772,6 +772,38 @@ extern "C" hipError_t qr_launch_pack_r (const QrPackRTask *d_tasks, const long l
 }
 
 // -----------------------------------------------------------------------------
+// rows of right-hand sides in and out of the fronts
+// -----------------------------------------------------------------------------
+//
+// dst [j * dstride] = src [j * sstride] for j < ncols, one (row, j) per thread: the rows of B scattered
+// to the right-hand-side blocks of the fronts (source strided by B's leading dimension), a child's
+// finished rows pushed into its parent's block, and the rows of Q'B gathered at the end
+// (destination strided).
+
+__global__ void __launch_bounds__ (QR_THREADS) k_copy_rows (const QrRowCopy *tasks, long long ntasks, int ncols,
+    long long sstride, long long dstride)
+{
+    const long long g = (long long) blockIdx.x * QR_THREADS + threadIdx.x ;
+    const long long row = g / ncols ;
+    const int j = (int) (g - row * ncols) ;
+    if (row < ntasks)
+    {
+        const QrRowCopy t = tasks [row] ;
+        ((gdouble *) t.dst) [j * dstride] = ((gcdouble *) t.src) [j * sstride] ;
+    }
+}
+
+extern "C" hipError_t qr_launch_copy_rows (const QrRowCopy *d_tasks, long long ntasks, int ncols,
+    long long sstride, long long dstride, hipStream_t stream)
+{
+    if (ntasks <= 0 || ncols <= 0) return hipSuccess ;
+    const long long nb = (ntasks * ncols + QR_THREADS - 1) / QR_THREADS ;
+    if (nb > 0x7fffffffLL) return hipErrorInvalidValue ;
+    hipLaunchKernelGGL (k_copy_rows, dim3 ((unsigned) nb), dim3 (QR_THREADS), 0, stream, d_tasks, ntasks, ncols, sstride, dstride) ;
+    return hipGetLastError ( ) ;
+}
+
+// -----------------------------------------------------------------------------
 // kernels: one per task kind and row tier, so each gets its own register budget
 // -----------------------------------------------------------------------------
 

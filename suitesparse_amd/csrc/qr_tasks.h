@@ -96,6 +96,13 @@ struct QrPackRTask
     int32_t       ld, fn, frank, pad;
 };
 
+// One row of a right-hand-side block on its way in, up the tree, or out.
+struct QrRowCopy
+{
+    const double *src;
+    double       *dst;
+};
+
 #define QR_QUEUE_HEAD   0       // counters[0]: next ticket
 #define QR_QUEUE_ERROR  1       // counters[1]: nonzero after a spin ran out (no task hangs the device)
 #define QR_QUEUE_FIRST  2       // counters[2 + c]: arrivals at counter c

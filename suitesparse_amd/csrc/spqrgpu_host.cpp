@@ -418,6 +418,27 @@ extern "C" void spqrgpu_amd_finalize (void)
     if (cur >= 0) (void) hipSetDevice (cur) ;
 }
 
+struct gpuqr_replay ;
+struct QrRowCopy { const double *src ; double *dst ; } ;        // = qr_tasks.h
+extern "C" hipError_t qr_launch_copy_rows (const QrRowCopy *d_tasks, long long ntasks, int ncols,
+    long long sstride, long long dstride, hipStream_t stream) ;
+
+// A factorization that keeps H (spqrgpu_amd_factorize_keep): the front arena with the Householder
+// vectors in place and a right-hand-side block of nrhs columns behind every front, the engine's
+// replay object (VT tiles, update tasks of the blocks), and the three row lists that take a
+// right-hand side through the tree: rows of B into the blocks, finished rows of a child into its
+// parent's block (by the round after which they are final), rows of Q'B out.
+struct spqr_amd_qt
+{
+    int device = -1 ;
+    Long m = 0, n = 0, nrhs = 0, rank = 0 ;
+    Buf dF, dB, dC, dScatter, dPush, dGather ;
+    gpuqr_replay *rp = NULL ;
+    Long nscatter = 0, ngather = 0 ;
+    hostvec<Long> push_ptr ;        // pushes that follow round r: [push_ptr [r], push_ptr [r+1])
+    ~spqr_amd_qt ( ) { if (rp) gpuqr_replay_free (rp) ; }
+} ;
+
 // What a factorization with a tolerance knows after its first pass: which pivot columns are dead.
 // A front with dead columns is factorized again with its columns in the order
 // [live pivot columns | non-pivot columns | dead pivot columns]: the live ones are reduced first, on
@@ -485,7 +506,7 @@ static int factorize_impl
 (
     const spqr_amd_symbolic *S, const int64_t *Ap, const int64_t *Ai, const double *Ax,
     const char *mine, const double *const *limbo_in, const bool limbo_in_dev, double *c_out_dev,
-    double *Rstack_user, int64_t Rstack_room, const RankPlan *rp,
+    double *Rstack_user, int64_t Rstack_room, const RankPlan *rp, spqr_amd_qt *keep,
     spqr_amd_numeric **num_out
 )
 {
@@ -506,7 +527,8 @@ static int factorize_impl
     int wdev = 0 ;
     if (hipGetDevice (&wdev) != hipSuccess || wdev < 0 || wdev >= MAX_WS_DEVICES) { host_free (num) ; return 2 ; }
     Workspaces &WS = g_ws [wdev] ;
-    Buf &dF = WS.dF, &dS = WS.dS, &dAx = WS.dAx, &dTasks = WS.dTasks, &dPrefix = WS.dPrefix ;
+    // (a factorization that keeps H owns its front arena: the fronts must outlive the call)
+    Buf &dF = keep ? keep->dF : WS.dF, &dS = WS.dS, &dAx = WS.dAx, &dTasks = WS.dTasks, &dPrefix = WS.dPrefix ;
     // A pageable R stack is filled through bounce buffers; between groups that copy runs on a thread of
     // its own beside the next group, which then packs its R into the other of two device blocks.
     std::thread r_thread ;
@@ -609,10 +631,18 @@ static int factorize_impl
         // of algorithmic bytes).
         static Long line_from = -1 ;
         if (line_from < 0) { const char *e = getenv ("GPUQR_LINE_ALIGN_FROM") ; line_from = e ? atol (e) : 96 ; }
+        hostvec<Long> rhs_col ((size_t) std::max ((Long) 1, nf), 0) ;
+        const Long rhs_n = keep ? keep->nrhs : 0 ;
         for (Long f = 0 ; f < nf ; f++)
         {
             const Long fn = Rp [f+1] - Rp [f] ;
             pitch [f] = (line_from > 0 && fn >= line_from) ? ((fn + 15) & ~(Long) 15) : (fn + (fn & 1)) ;
+            if (keep)
+            {
+                // the right-hand-side block sits behind the front's columns, on a 128-byte line
+                rhs_col [f] = (fn + 15) & ~(Long) 15 ;
+                pitch [f] = rhs_col [f] + ((rhs_n + 15) & ~(Long) 15) ;
+            }
         }
 
         // ---- groups ------------------------------------------------------------------------------
@@ -654,6 +684,7 @@ static int factorize_impl
             }
             ngroups = open ? g + 1 : 0 ;
         }
+        if (keep && (ngroups != 1 || mine || rp)) { code = 3 ; goto done ; }      // H is kept for single-stage factorizations only
 
         // ---- layout of a group --------------------------------------------------------------------
         hostvec<Long> list, FOff, SOff, ROff ;
@@ -712,7 +743,7 @@ static int factorize_impl
 
         Long rhead = 0, chead = 0 ;
         // With a page-locked stack the engine itself packs R and sends it (GPUQR_LATE_R: afterwards, in one copy)
-        const bool r_in_engine = num->RstackPinned && getenv ("GPUQR_LATE_R") == NULL ;
+        const bool r_in_engine = num->RstackPinned && !keep && getenv ("GPUQR_LATE_R") == NULL ;
         hostvec<PackRTask> ptasks ;
         hostvec<long long> prefix ;
         hostvec<double> rows_host ;             // unpacked R rows of the group's fronts with dead columns
@@ -783,6 +814,7 @@ static int factorize_impl
                     fr.cpuRpack = num->Rstack + rhead + ROff [k] ;
                 }
                 fr.is_sparse = 1 ;
+                fr.rhs_col = (int32_t) rhs_col [f] ; fr.rhs_n = (int32_t) rhs_n ;
                 fr.nc = (int32_t) (Childp [f+1] - Childp [f]) ;
                 fr.Scount = S_count (f) ;
                 fr.gpuS = S0 + SOff [k] ;
@@ -866,7 +898,8 @@ static int factorize_impl
                 if (mine) for (Long f = 0 ; f < nf ; f++) { plan_key ^= (uint64_t) (mine [f] != 0) ; plan_key *= 1099511628211ull ; }
                 plan_key |= 1 ;
             }
-            int ecode = gpuqr_factor_sparse_keyed (S->gpuMemorySize, fronts.data ( ), next_child, Parent, Childp, Child, &stats, plan_key) ;
+            int ecode = keep ? gpuqr_factor_sparse_keep (fronts.data ( ), next_child, &stats, &keep->rp)
+                : gpuqr_factor_sparse_keyed (S->gpuMemorySize, fronts.data ( ), next_child, Parent, Childp, Child, &stats, plan_key) ;
             TICK ("engine") ;
             if (ecode != GPUQR_SUCCESS) { code = (ecode == GPUQR_OUTOFMEMORY) ? 1 : 2 ; goto done ; }
             num->gpuKernelTime += stats.kernelTime ;
@@ -1008,6 +1041,81 @@ static int factorize_impl
                 }
             }
             TICK ("R pack + copy") ;
+
+            if (keep)
+            {
+                // ---- the three row lists of Q'B ------------------------------------------------------
+                hostvec<QrRowCopy> scat, push, gath ;
+                hostvec<Long> push_round ;
+                // rows of S (= rows of A, permuted) into the fronts: S row `row` sits in front row
+                // findex / fn of its first entry; entries are packed front by front in postorder,
+                // pivot column by pivot column, row by row (spqrgpu_amd_build_assembly_maps)
+                hostvec<Long> findex ((size_t) std::max ((Long) 1, S->anz)) ;
+                if (S->anz > 0) HIPCHK (hipMemcpy (findex.data ( ), NC.d_findex, (size_t) S->anz * sizeof (Long), hipMemcpyDeviceToHost)) ;
+                hostvec<Long> P ((size_t) std::max ((Long) 1, S->m), 0) ;
+                for (Long i = 0 ; i < S->m ; i++) P [S->PLinv [i]] = i ;
+                const double *dB = (const double *) keep->dB.p ;
+                Long q = 0 ;
+                for (Long kk = 0 ; kk < nf ; kk++)
+                {
+                    const Long f = Post [kk], k = rel [f] ;
+                    const Long fn = Rp [f+1] - Rp [f] ;
+                    double *Ff = F0 + FOff [k] ;
+                    for (Long row = Sleft [Super [f]] ; row < Sleft [Super [f+1]] ; row++)
+                    {
+                        if (Sp [row+1] > Sp [row])
+                        {
+                            const Long i = findex [q] / fn ;
+                            QrRowCopy t ; t.src = dB + P [row] ; t.dst = Ff + i * pitch [f] + rhs_col [f] ;
+                            scat.push_back (t) ;
+                        }
+                        q += Sp [row+1] - Sp [row] ;
+                    }
+                }
+                Long row1 = 0 ;
+                const int32_t nrounds = gpuqr_replay_rounds (keep->rp) ;
+                for (Long f = 0 ; f < nf ; f++)
+                {
+                    const Long k = rel [f], frank = rank_of (f), pid = Parent [f] ;
+                    double *Ff = F0 + FOff [k] ;
+                    for (Long i = 0 ; i < frank ; i++)
+                    {
+                        QrRowCopy t ; t.src = Ff + i * pitch [f] + rhs_col [f] ; t.dst = (double *) keep->dC.p + row1 + i ;
+                        gath.push_back (t) ;
+                    }
+                    row1 += frank ;
+                    if (pid < nf)
+                    {
+                        double *Fp = F0 + FOff [rel [pid]] ;
+                        const int32_t *Rimap = NC.Rimap.data ( ) + S->RimapOffsets [f] ;
+                        const Long after = gpuqr_replay_front_done (keep->rp, k) ;
+                        for (Long i = 0 ; i < cm_of (f) ; i++)
+                        {
+                            QrRowCopy t ; t.src = Ff + (frank + i) * pitch [f] + rhs_col [f] ;
+                            t.dst = Fp + (Long) Rimap [i] * pitch [pid] + rhs_col [pid] ;
+                            push.push_back (t) ;
+                            push_round.push_back (std::max ((Long) 0, std::min ((Long) nrounds - 1, after))) ;
+                        }
+                    }
+                }
+                // pushes by the round they follow (counting sort)
+                keep->push_ptr.assign ((size_t) nrounds + 2, 0) ;
+                for (size_t i = 0 ; i < push.size ( ) ; i++) keep->push_ptr [push_round [i] + 1]++ ;
+                for (int32_t r = 0 ; r <= nrounds ; r++) keep->push_ptr [r+1] += keep->push_ptr [r] ;
+                hostvec<QrRowCopy> sorted (std::max (push.size ( ), (size_t) 1)) ;
+                {
+                    hostvec<Long> pos (keep->push_ptr) ;
+                    for (size_t i = 0 ; i < push.size ( ) ; i++) sorted [pos [push_round [i]]++] = push [i] ;
+                }
+                keep->nscatter = (Long) scat.size ( ) ; keep->ngather = (Long) gath.size ( ) ; keep->rank = row1 ;
+                if (keep->dScatter.ensure (std::max (scat.size ( ), (size_t) 1) * sizeof (QrRowCopy)) != hipSuccess
+                 || keep->dPush.ensure (sorted.size ( ) * sizeof (QrRowCopy)) != hipSuccess
+                 || keep->dGather.ensure (std::max (gath.size ( ), (size_t) 1) * sizeof (QrRowCopy)) != hipSuccess) { code = 1 ; goto done ; }
+                HIPCHK (hipMemcpy (keep->dScatter.p, scat.data ( ), scat.size ( ) * sizeof (QrRowCopy), hipMemcpyHostToDevice)) ;
+                HIPCHK (hipMemcpy (keep->dPush.p, sorted.data ( ), push.size ( ) * sizeof (QrRowCopy), hipMemcpyHostToDevice)) ;
+                HIPCHK (hipMemcpy (keep->dGather.p, gath.data ( ), gath.size ( ) * sizeof (QrRowCopy), hipMemcpyHostToDevice)) ;
+                TICK ("row lists of the kept factorization") ;
+            }
         }
 
         // ---- ranks and dead columns (no rank detection on the device) ----------------------------
@@ -1044,7 +1152,7 @@ extern "C" int spqrgpu_amd_factorize
 )
 {
     if (!S || !Ap || !Ax || !num_out || (!Ai && S->anz > 0)) return 3 ;
-    return factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, NULL, num_out) ;
+    return factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, NULL, NULL, num_out) ;
 }
 
 // -----------------------------------------------------------------------------
@@ -1166,10 +1274,10 @@ extern "C" int spqrgpu_amd_factorize_tol
 )
 {
     if (!S || !Ap || !Ax || !num_out || (!Ai && S->anz > 0)) return 3 ;
-    if (tol < 0) return factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, NULL, num_out) ;
+    if (tol < 0) return factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, NULL, NULL, num_out) ;
     if (!S->do_rank_detection) return 3 ;           // the fronts have no room for rows that dead columns free
     spqr_amd_numeric *num = NULL ;
-    int code = factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, NULL, &num) ;
+    int code = factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, NULL, NULL, &num) ;
     if (code != 0) return code ;
     try
     {
@@ -1182,7 +1290,7 @@ extern "C" int spqrgpu_amd_factorize_tol
             num = NULL ;
             RankPlan rp ;
             code = build_rank_plan (S, dead.data ( ), rp) ;
-            if (code == 0) code = factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, &rp, &num) ;
+            if (code == 0) code = factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, &rp, NULL, &num) ;
             if (code != 0) return code ;
             passes++ ;
         }
@@ -1195,6 +1303,94 @@ extern "C" int spqrgpu_amd_factorize_tol
     }
     *num_out = num ;
     return 0 ;
+}
+
+// -----------------------------------------------------------------------------
+// H kept on the device: Q'B for right-hand sides that arrive after the factorization
+// -----------------------------------------------------------------------------
+
+extern "C" void spqr_amd_qt_free (spqr_amd_qt *qt)
+{
+    if (!qt) return ;
+    int cur = -1 ;
+    (void) hipGetDevice (&cur) ;
+    if (qt->device >= 0 && qt->device != cur) (void) hipSetDevice (qt->device) ;
+    qt->~spqr_amd_qt ( ) ;
+    host_free (qt) ;
+    if (cur >= 0 && qt->device != cur) (void) hipSetDevice (cur) ;
+}
+
+extern "C" int spqrgpu_amd_factorize_keep
+(
+    const spqr_amd_symbolic *S, const int64_t *Ap, const int64_t *Ai, const double *Ax, int64_t nrhs,
+    spqr_amd_numeric **num_out, spqr_amd_qt **qt_out
+)
+{
+    if (qt_out) *qt_out = NULL ;
+    if (!S || !Ap || !Ax || !num_out || !qt_out || (!Ai && S->anz > 0) || nrhs < 1 || nrhs > 256) return 3 ;
+    if (S->do_rank_detection || (Long) S->PLinv.size ( ) < S->m) return 3 ;
+    spqr_amd_qt *qt = (spqr_amd_qt *) host_calloc (1, sizeof (spqr_amd_qt)) ;
+    if (!qt) return 1 ;
+    new (qt) spqr_amd_qt ( ) ;
+    int code = 0 ;
+    if (hipGetDevice (&qt->device) != hipSuccess) code = 2 ;
+    qt->m = S->m ; qt->n = S->n ; qt->nrhs = nrhs ;
+    // B and Q'B on the device; sized before the factorization, whose row lists point into them
+    Long rank = 0 ;
+    for (Long f = 0 ; f < S->nf ; f++) rank += std::min (S->Fm [f], S->Super [f+1] - S->Super [f]) ;
+    if (code == 0 && (qt->dB.ensure ((size_t) std::max ((Long) 1, S->m * nrhs) * sizeof (double)) != hipSuccess
+        || qt->dC.ensure ((size_t) std::max ((Long) 1, rank * nrhs) * sizeof (double)) != hipSuccess)) code = 1 ;
+    if (code == 0)
+    {
+        try { code = factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, NULL, qt, num_out) ; }
+        catch (std::bad_alloc &) { code = 1 ; }
+    }
+    if (code != 0) { spqr_amd_qt_free (qt) ; return code ; }
+    *qt_out = qt ;
+    return 0 ;
+}
+
+extern "C" int64_t spqr_amd_qt_rank (const spqr_amd_qt *qt) { return qt ? qt->rank : -1 ; }
+
+// C = the first `rank` rows of Q'B, in the row order of R (the rows a solve needs: R x = C), for B
+// m-by-nrhs: the rows of B go to the right-hand-side blocks of the fronts that hold the matching
+// rows of S, every front's block reflectors are applied to its block in the rounds of the
+// factorization's own schedule, a front's rows below its rank go on to its parent's block, and the
+// rows above it are the result.  What SuiteSparseQR_qmult (SPQR_QTX) does with H on the host
+// (SPQR/Source/SuiteSparseQR_qmult.cpp, spqr_happly.cpp), restricted to the rows of R.
+extern "C" int spqrgpu_amd_qtmult
+(
+    spqr_amd_qt *qt, const double *B, int64_t ldb, double *C, int64_t ldc
+)
+{
+    if (!qt || !qt->rp || !B || !C || ldb < qt->m || ldc < qt->rank) return 3 ;
+    int code = 0 ;
+    int cur = -1 ;
+    if (hipGetDevice (&cur) != hipSuccess || cur != qt->device) return 3 ;
+    const Long m = qt->m, k = qt->nrhs ;
+    if (ldb == m) HIPCHK (hipMemcpyAsync (qt->dB.p, B, (size_t) (m * k) * sizeof (double), hipMemcpyHostToDevice, 0)) ;
+    else HIPCHK (hipMemcpy2DAsync (qt->dB.p, (size_t) m * sizeof (double), B, (size_t) ldb * sizeof (double),
+        (size_t) m * sizeof (double), (size_t) k, hipMemcpyHostToDevice, 0)) ;
+    HIPCHK (qr_launch_copy_rows ((const QrRowCopy *) qt->dScatter.p, qt->nscatter, (int) k, m, 1, 0)) ;
+    {
+        const int32_t nrounds = gpuqr_replay_rounds (qt->rp) ;
+        for (int32_t r = 0 ; r < nrounds ; r++)
+        {
+            if (gpuqr_replay_round (qt->rp, r, (void *) 0) != GPUQR_SUCCESS) { code = 2 ; goto done ; }
+            const Long p0 = qt->push_ptr [r], p1 = qt->push_ptr [r+1] ;
+            if (p1 > p0) HIPCHK (qr_launch_copy_rows ((const QrRowCopy *) qt->dPush.p + p0, p1 - p0, (int) k, 1, 1, 0)) ;
+        }
+    }
+    HIPCHK (qr_launch_copy_rows ((const QrRowCopy *) qt->dGather.p, qt->ngather, (int) k, 1, qt->rank, 0)) ;
+    if (qt->rank > 0)
+    {
+        if (ldc == qt->rank) HIPCHK (hipMemcpyAsync (C, qt->dC.p, (size_t) (qt->rank * k) * sizeof (double), hipMemcpyDeviceToHost, 0)) ;
+        else HIPCHK (hipMemcpy2DAsync (C, (size_t) ldc * sizeof (double), qt->dC.p, (size_t) qt->rank * sizeof (double),
+            (size_t) qt->rank * sizeof (double), (size_t) k, hipMemcpyDeviceToHost, 0)) ;
+    }
+done:
+    if (hipStreamSynchronize (0) != hipSuccess && code == 0) code = 2 ;
+    return code ;
 }
 
 // What SPQR's numeric phase hands to spqrgpu_kernel and takes back from it, on plain arrays
@@ -1214,7 +1410,7 @@ extern "C" int spqrgpu_amd_kernel
 {
     if (!S || (!Sx && S->anz > 0) || (!Stack_head && S->rnz > 0) || !Rblock_offset || !Rdead) return 3 ;
     spqr_amd_numeric *num = NULL ;
-    const int code = factorize_impl (S, NULL, NULL, Sx, NULL, NULL, false, NULL, Stack_head, stack_room, NULL, &num) ;
+    const int code = factorize_impl (S, NULL, NULL, Sx, NULL, NULL, false, NULL, Stack_head, stack_room, NULL, NULL, &num) ;
     if (code != 0) return code ;
     for (Long f = 0 ; f < S->nf ; f++) Rblock_offset [f] = num->Rblock [f] ;
     for (Long k = 0 ; k < S->n ; k++) if (num->Rdead [k]) Rdead [k] = 1 ;
@@ -1295,7 +1491,7 @@ extern "C" int spqrgpu_amd_factorize_subset
 )
 {
     if (!S || !Ap || !Ax || !mine || !num_out || (!Ai && S->anz > 0)) return 3 ;
-    return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in, false, NULL, NULL, 0, NULL, num_out) ;
+    return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in, false, NULL, NULL, 0, NULL, NULL, num_out) ;
 }
 
 // The same with the contribution blocks staying on the device on both sides: limbo_in[c] are device
@@ -1310,7 +1506,7 @@ extern "C" int spqrgpu_amd_factorize_subset_dev
 {
     if (!S || !Ap || !Ax || !mine || !num_out || (!Ai && S->anz > 0)) return 3 ;
     if (!c_out_dev && spqrgpu_amd_subset_csize (S, mine) > 0) return 3 ;
-    return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in_dev, true, c_out_dev, NULL, 0, NULL, num_out) ;
+    return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in_dev, true, c_out_dev, NULL, 0, NULL, NULL, num_out) ;
 }
 
 // Doubles of contribution blocks that leave a subset call: the fronts of the subset whose parent is

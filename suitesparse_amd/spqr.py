@@ -306,3 +306,80 @@ def spqrgpu_kernel(sym, Sx, stack_room=None):
                                 C.byref(maxfrank), C.byref(used), C.byref(kms), C.byref(flops), C.byref(launches))
     return dict(code=code, stack=stack, Rblock=Rblock, Rdead=Rdead, sumfrank=sumfrank.value, maxfrank=maxfrank.value,
                 used=used.value, kernel_ms=kms.value, flops=flops.value, launches=launches.value)
+
+
+class KeptFactorization:
+    """spqrgpu_amd_factorize_keep: R plus H kept on the device, for Q'B and solves with right-hand
+    sides that arrive later (SuiteSparseQR_factorize + SuiteSparseQR_qmult / _solve in the reference's
+    expert interface, SPQR/Source/SuiteSparseQR_expert.cpp:324-343, which its GPU path cannot serve)."""
+
+    def __init__(self, sym, A, nrhs=1):
+        L = _bind()
+        self.sym, self.nrhs = sym, int(nrhs)
+        A = sp.csc_matrix(A)
+        A.sort_indices()
+        Ap, Ai, Ax = _i64(A.indptr), _i64(A.indices), np.ascontiguousarray(A.data, dtype=np.float64)
+        out = C.POINTER(Numeric)()
+        self._qt = C.c_void_p(0)
+        L.spqrgpu_amd_factorize_keep.restype = C.c_int
+        L.spqrgpu_amd_factorize_keep.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                                 C.POINTER(C.POINTER(Numeric)), C.POINTER(C.c_void_p)]
+        code = L.spqrgpu_amd_factorize_keep(sym._h, _p(Ap), _p(Ai), _p(Ax), self.nrhs, C.byref(out), C.byref(self._qt))
+        if code != 0:
+            raise RuntimeError("spqrgpu_amd_factorize_keep failed with code %d" % code)
+        n = sym.n
+        Rp = np.zeros(n + 1, dtype=np.int64)
+        L.spqr_amd_rconvert(sym._h, out, _p(Rp), None, None)
+        Ri = np.zeros(max(int(Rp[n]), 1), dtype=np.int64)
+        Rx = np.zeros(max(int(Rp[n]), 1), dtype=np.float64)
+        L.spqr_amd_rconvert(sym._h, out, _p(Rp), _p(Ri), _p(Rx))
+        self.rank = int(out.contents.sumfrank)
+        self.R = sp.csc_matrix((Rx[:Rp[n]], Ri[:Rp[n]], Rp), shape=(self.rank, n))
+        L.spqr_amd_numeric_free(out)
+        L.spqr_amd_qt_rank.restype = C.c_int64
+        L.spqr_amd_qt_rank.argtypes = [C.c_void_p]
+        assert L.spqr_amd_qt_rank(self._qt) == self.rank
+
+    def qtmult(self, B):
+        """The first rank rows of Q'B (rows in the order of R), B m-by-k with k <= nrhs."""
+        L = _bind()
+        m = self.sym.m
+        B = np.asarray(B, dtype=np.float64).reshape(m, -1)
+        k = B.shape[1]
+        if k > self.nrhs:
+            raise ValueError("more right-hand sides than the factorization was kept for")
+        Bf = np.zeros((m, self.nrhs), order="F")
+        Bf[:, :k] = B
+        Cf = np.zeros((max(self.rank, 1), self.nrhs), order="F")
+        L.spqrgpu_amd_qtmult.restype = C.c_int
+        L.spqrgpu_amd_qtmult.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        code = L.spqrgpu_amd_qtmult(self._qt, _p(Bf), m, _p(Cf), max(self.rank, 1))
+        if code != 0:
+            raise RuntimeError("spqrgpu_amd_qtmult failed with code %d" % code)
+        return Cf[:self.rank, :k].copy()
+
+    def solve(self, B):
+        """min ||A x - B||_2 for a full-column-rank A: x = E (R \\ (Q'B)), back substitution on the host
+        as spqr_rsolve does it in the reference (SPQR/Source/spqr_rsolve.cpp)."""
+        from scipy.sparse.linalg import spsolve_triangular
+        n = self.sym.n
+        if self.rank < n:
+            raise np.linalg.LinAlgError("rank %d < %d" % (self.rank, n))
+        Cq = self.qtmult(B)
+        y = spsolve_triangular(self.R.tocsr(), Cq, lower=False)
+        x = np.zeros_like(y)
+        x[self.sym.Qfill[:n]] = y
+        return x
+
+    def close(self):
+        if getattr(self, "_qt", None) and self._qt.value:
+            L = _bind()
+            L.spqr_amd_qt_free.argtypes = [C.c_void_p]
+            L.spqr_amd_qt_free(self._qt)
+            self._qt = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -441,3 +441,46 @@ def test_rank_detection_needs_its_analysis_and_costs_nothing_at_full_rank():
     assert res.numPasses == 1 and res.rank == sym.n and res.Rdead.sum() == 0
     assert np.abs(res.R - ref.R).max() <= 1e-13 * np.abs(ref.R).max()
     assert (spqr.factorize(sym, A, tol=-1.0).R != spqr.factorize(sym, A).R).nnz == 0
+
+
+@pytest.mark.parametrize("shape,leaf,nrhs", [((24, 24), 4, 3), ((9, 9, 9), 2, 1), ((14, 14, 14), 3, 17), ((40, 40), 4, 32)])
+def test_h_kept_on_the_device_qtmult_and_solve(shape, leaf, nrhs):
+    """Factor once, keep H on the device, then push right-hand sides through it that were not known at
+    factorization time: C = (Q'B)(0:n,:) against a dense Q (row signs fixed by R's diagonal), and
+    x = R \\ C against the least-squares solution; twice, with different B, on the same object; and
+    the same R as the ordinary factorization."""
+    A = problems.stacked_ls(shape)
+    Q = problems.nested_dissection(shape, leaf=leaf)
+    sym = spqr.analyze(A, Q, relax=20, gpuMemorySize=2**34)
+    m, n = A.shape
+    kept = spqr.KeptFactorization(sym, A, nrhs=nrhs)
+    plain = spqr.factorize(sym, A)
+    assert kept.rank == n
+    assert np.abs(kept.R - plain.R).max() <= 1e-13 * np.abs(plain.R).max()
+    AQ = A[:, sym.Qfill].toarray()
+    Qd, Rd = np.linalg.qr(AQ, mode="reduced")
+    sgn = np.where(np.diag(Rd) < 0, -1.0, 1.0)          # the device's R has a non-negative diagonal
+    rng = np.random.default_rng(3)
+    for trial in range(2):
+        k = nrhs if trial == 0 else max(1, nrhs // 2)
+        B = rng.standard_normal((m, k))
+        Cq = kept.qtmult(B)
+        ref = (Qd * sgn).T @ B
+        assert np.abs(Cq - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1.0)
+        x = kept.solve(B)
+        xl = np.linalg.lstsq(A.toarray(), B, rcond=None)[0]
+        assert np.abs(x - xl).max() <= 1e-10 * max(np.abs(xl).max(), 1.0)
+    kept.close()
+
+
+def test_h_kept_refuses_what_it_cannot_serve():
+    A = problems.stacked_ls((12, 12))
+    Q = problems.nested_dissection((12, 12), leaf=3)
+    staged = spqr.analyze(A, Q, gpuMemorySize=0)              # one front per stage: the fronts are not all resident
+    with pytest.raises(RuntimeError):
+        spqr.KeptFactorization(staged, A, nrhs=1)
+    rd = spqr.analyze(A, Q, gpuMemorySize=2**33, rank_detection=True)
+    with pytest.raises(RuntimeError):
+        spqr.KeptFactorization(rd, A, nrhs=1)
+    with pytest.raises(RuntimeError):
+        spqr.KeptFactorization(spqr.analyze(A, Q, gpuMemorySize=2**33), A, nrhs=1000)
