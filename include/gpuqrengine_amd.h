@@ -80,6 +80,11 @@ typedef struct gpuqr_front
      * Every panel's block reflector is applied to them; they are never factorized.  rhs_n = 0: none. */
     int32_t rhs_col;
     int32_t rhs_n;
+    /* Host copy of gpuRimap (size cm), optional, no counterpart in the reference's Front.  With it the
+     * engine knows which rows of the parent each block of C rows lands in, sends the rows of C to the
+     * parent as soon as they are final and lets the parent's first panels start while this front is
+     * still working on its later ones.  NULL: the parent waits for the whole front. */
+    const int32_t *cpuRimap;
 } gpuqr_front;
 
 /* same fields as QREngineStats (GPUQREngine/Include/GPUQREngine_Stats.hpp:13-29) */

@@ -30,6 +30,7 @@ class FrontC(C.Structure):
         ("gpuRjmap", C.c_void_p), ("gpuRimap", C.c_void_p), ("gpuC", C.c_void_p),
         ("gpuRpack", C.c_void_p), ("cpuRpack", C.c_void_p),
         ("rhs_col", C.c_int32), ("rhs_n", C.c_int32),
+        ("cpuRimap", C.c_void_p),
     ]
 
 

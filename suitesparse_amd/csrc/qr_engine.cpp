@@ -275,13 +275,21 @@ static int lookahead_min_tiles (void)
     return v ;
 }
 
+// A block of contribution-block rows that lands in a front: the first (lowest) row of the front
+// it writes, and the round of its pack-assembly tasks.  Later rows of the block land further down.
+struct AsmEvent { int32_t min_row, round ; } ;
+
 // Emit all factorize/apply tasks of one front.  last [c] is, on entry, the latest round of class c
 // whose work the front's first tasks must wait for (assembly into it), and on return the latest
 // round of class c used by the front.  Every task gets round = 1 + the latest round it depends on.
+// ev [0..nev), sorted by min_row: assembly that the front's panels wait for one by one, a panel
+// only for the blocks that reach into the rows it works on.  rows_done (optional) receives, per
+// panel and class, the latest round after which the rows of the panel's diagonal block are final.
 static void plan_front
 (
     Plan &plan, double *F, int64_t fm, int64_t fn, int64_t ld, const int64_t *Stair,
-    int32_t last [QR_NCLASS], bool emit, int64_t rhs_col = 0, int64_t rhs_n = 0
+    int32_t last [QR_NCLASS], bool emit, int64_t rhs_col = 0, int64_t rhs_n = 0,
+    const AsmEvent *ev = NULL, size_t nev = 0, hvec<int32_t> *rows_done = NULL
 )
 {
     if (fm <= 0 || fn <= 0) return ;
@@ -298,6 +306,9 @@ static void plan_front
     hvec<Seg> tops, next ;
     int64_t e_prev = 0 ;
     const int la_min = lookahead_min_tiles ( ) ;
+    size_t ei = 0 ;             // assembly blocks [0, ei) reach into rows that some panel so far works on
+    int32_t asm_run = -1 ;      // latest round among them
+    if (rows_done) rows_done->assign ((size_t) npanels * QR_NCLASS, -1) ;
 
     for (int64_t p = 0 ; p < npanels ; p++)
     {
@@ -318,6 +329,8 @@ static void plan_front
         const int64_t m = e - r0 ;
         const bool trailing = (c0 + w < fn) ;
         const bool wants_vt = trailing || has_rhs ;
+        while (ei < nev && ev [ei].min_row < e) { asm_run = std::max (asm_run, ev [ei].round) ; ei++ ; }
+        last [2] = std::max (last [2], asm_run) ;
 
         // ---- factorize tasks, level by level ---------------------------------
         struct FRef { int64_t vt ; int32_t K ; int32_t nseg ; Seg segs [QR_MAX_SEG] ; int32_t level ; } ;
@@ -327,7 +340,12 @@ static void plan_front
         int32_t level = 0 ;
         int32_t depF [QR_NCLASS] ;
         int32_t rF0 = 0 ;
-        for (int c = 0 ; c < QR_NCLASS ; c++) { depF [c] = lastw [c][p] ; rF0 = std::max (rF0, depF [c] + 1) ; }
+        for (int c = 0 ; c < QR_NCLASS ; c++)
+        {
+            depF [c] = lastw [c][p] ;
+            if (c == 2) depF [c] = std::max (depF [c], asm_run) ;
+            rF0 = std::max (rF0, depF [c] + 1) ;
+        }
         for (int64_t c = 0 ; c < nchunks ; c++)
         {
             FRef fr ;
@@ -411,6 +429,7 @@ static void plan_front
                     for (int c = 0 ; c < QR_NCLASS ; c++)
                         for (int64_t t = ta ; t < tb ; t++) dep [c] = std::max (dep [c], lastw [c][t]) ;
                     dep [0] = std::max (dep [0], rF0 + lv) ;
+                    dep [2] = std::max (dep [2], asm_run) ;
                     const int32_t round = 1 + std::max (dep [0], std::max (dep [1], dep [2])) ;
                     int32_t used [QR_NCLASS] = {-1, -1, -1} ;
                     for (size_t i = 0 ; i < frefs.size ( ) ; i++)
@@ -459,6 +478,7 @@ static void plan_front
                 int32_t dep [QR_NCLASS] ;
                 for (int c = 0 ; c < QR_NCLASS ; c++) dep [c] = lastw [c][tr] ;
                 dep [0] = std::max (dep [0], rF0 + lv) ;
+                dep [2] = std::max (dep [2], asm_run) ;
                 const int32_t round = 1 + std::max (dep [0], std::max (dep [1], dep [2])) ;
                 int32_t used [QR_NCLASS] = {-1, -1, -1} ;
                 for (size_t i = 0 ; i < frefs.size ( ) ; i++)
@@ -497,6 +517,8 @@ static void plan_front
                 }
             }
         }
+        // everything that writes rows [c0, c0 + w) has been emitted by now
+        if (rows_done) for (int c = 0 ; c < QR_NCLASS ; c++) (*rows_done) [(size_t) p * QR_NCLASS + c] = last [c] ;
     }
 }
 
@@ -605,7 +627,9 @@ static DeviceCache *device_cache (void)
     if (!dc->ready)
     {
         // No stream priorities.  A high-priority panel stream bought under 1 % (its few long workgroups
-        // take the compute-unit slots that free up first), and with several processes on one device it
+        // take the compute-unit slots that free up first; measured again with contribution blocks
+        // travelling row block by row block: 88.4 against 87.9 ms on the 1024 x 1024 grid, 594 against
+        // 591 ms on the 64^3 grid), and with several processes on one device it
         // stalled all of them for good: every launch queued, no stream ever finishing, reproducibly
         // with three processes holding contexts and gone with equal priorities.  A high-priority queue
         // parked on a barrier packet that waits for a kernel of the same process's low-priority queue
@@ -1129,6 +1153,30 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
         // per front: latest round of each class that assembled into it; latest round of each class it used
         hvec<int32_t> in_last ((size_t) nf * QR_NCLASS, -1) ;
         done_last.assign ((size_t) nf * QR_NCLASS, -1) ;
+        // Contribution blocks travel to the parent in blocks of rows, each as soon as its rows are
+        // final, when the caller supplied the host copy of the row map (cpuRimap): the engine then
+        // knows the first parent row a block lands in, and a panel of the parent waits only for the
+        // blocks that reach into its rows.  Without the map, or with right-hand-side blocks (whose
+        // replays move rows between fronts front by front), the parent waits for the whole child.
+        // The work queue (modes 1 and 2) counts arrivals per front and takes "n arrivals" for "the first
+        // n tasks": a block of rows that arrives early would be counted in place of a task the front
+        // still waits for, so the queue keeps whole-front hand-overs.
+        bool pipelined = getenv ("GPUQR_NO_PIPELINE") == NULL && engine_mode ( ) == 0 ;
+        for (int64_t f = 0 ; f < nf && pipelined ; f++) if (fronts [f].rhs_n > 0) pipelined = false ;
+        static int pipe_rows = 0 ;
+        if (pipe_rows == 0)
+        {
+            const char *e = getenv ("GPUQR_PIPE_ROWS") ;
+            // rows per block: one panel's worth (measured on the 1024 x 1024 grid: 99.6 / 98.8 / 96.9 ms with
+            // 128 / 64 / 32 rows; the 64^3 grid: 660 / 598 / 596 ms)
+            pipe_rows = e ? atoi (e) : QR_PANEL_W ;
+            if (pipe_rows < QR_PANEL_W || pipe_rows > QR_PACK_TILE || pipe_rows % QR_PANEL_W) pipe_rows = QR_PANEL_W ;
+        }
+        struct EvNode { AsmEvent ev ; int64_t next ; } ;
+        hvec<EvNode> evpool ;
+        hvec<int64_t> ev_head ((size_t) nf, -1) ;
+        hvec<AsmEvent> evs ;
+        hvec<int32_t> rows_done ;
         for (size_t k = 0 ; k < order.size ( ) ; k++)
         {
             const int64_t f = order [k] ;
@@ -1136,6 +1184,10 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
             const size_t first_task = plan.tasks.size ( ) ;
             int32_t last [QR_NCLASS] ;
             for (int c = 0 ; c < QR_NCLASS ; c++) last [c] = in_last [f*QR_NCLASS + c] ;
+            evs.clear ( ) ;
+            for (int64_t q = ev_head [f] ; q >= 0 ; q = evpool [q].next) evs.push_back (evpool [q].ev) ;
+            std::sort (evs.begin ( ), evs.end ( ), [] (const AsmEvent &a, const AsmEvent &b) { return a.min_row < b.min_row ; }) ;
+            rows_done.clear ( ) ;
             if (!(fr.is_sparse && fr.push_only))
             {
                 // S assembly, round 0
@@ -1157,8 +1209,11 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
                     }
                     if (fr.Scount > 0) last [2] = std::max (last [2], 0) ;
                 }
-                plan_front (plan, fr.gpuF, fr.fm, fr.fn, front_pitch (fr), fr.Stair, last, true, fr.rhs_col, fr.rhs_n) ;
+                plan_front (plan, fr.gpuF, fr.fm, fr.fn, front_pitch (fr), fr.Stair, last, true, fr.rhs_col, fr.rhs_n,
+                    evs.data ( ), evs.size ( ), &rows_done) ;
             }
+            // blocks that no panel reached into (rows below every panel's) still belong to the front
+            for (size_t q = 0 ; q < evs.size ( ) ; q++) last [2] = std::max (last [2], evs [q].round) ;
             for (int c = 0 ; c < QR_NCLASS ; c++) done_last [f*QR_NCLASS + c] = last [c] ;
             for (size_t i = first_task ; i < plan.tasks.size ( ) ; i++)
             {
@@ -1167,10 +1222,32 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
             // pack assembly into the parent
             if (fr.is_sparse && fr.pids >= 0 && fr.cm > 0 && fr.cn > 0)
             {
-                const int32_t round = 1 + std::max (last [0], std::max (last [1], last [2])) ;
                 const int32_t cld = fr.push_only ? fr.cn : (int32_t) front_pitch (fr) ;
-                for (int32_t ci = 0 ; ci < fr.cm ; ci += QR_PACK_TILE)
+                // first row of C inside the front (when C lies inside it, which the engine cannot take for granted)
+                int64_t crow0 = -1 ;
+                const bool by_rows = pipelined && fr.cpuRimap != NULL ;
+                if (by_rows && !fr.push_only && !rows_done.empty ( ) && fr.gpuC >= fr.gpuF)
                 {
+                    const int64_t off = (int64_t) (fr.gpuC - fr.gpuF) ;
+                    const int64_t r = off / front_pitch (fr) ;
+                    const int64_t mn = std::min (fr.fm, fr.fn) ;
+                    if (r + fr.cm <= mn) crow0 = r ;
+                }
+                const int32_t rstep = by_rows ? pipe_rows : QR_PACK_TILE ;
+                int32_t round_max = -1 ;
+                for (int32_t ci = 0 ; ci < fr.cm ; ci += rstep)
+                {
+                    const int32_t ciend = std::min (ci + rstep, fr.cm) ;
+                    int32_t dep [QR_NCLASS] ;
+                    for (int c = 0 ; c < QR_NCLASS ; c++) dep [c] = last [c] ;
+                    if (crow0 >= 0)
+                    {
+                        // the rows of this block are final once the panel of its last row is through
+                        const int64_t pl = (crow0 + ciend - 1) / QR_PANEL_W ;
+                        for (int c = 0 ; c < QR_NCLASS ; c++) dep [c] = rows_done [(size_t) pl * QR_NCLASS + c] ;
+                    }
+                    const int32_t round = 1 + std::max (dep [0], std::max (dep [1], dep [2])) ;
+                    round_max = std::max (round_max, round) ;
                     for (int32_t cj = (ci / QR_PACK_TILE) * QR_PACK_TILE ; cj < fr.cn ; cj += QR_PACK_TILE)
                     {
                         SchedTask st ; memset (&st, 0, sizeof (st)) ;
@@ -1180,10 +1257,10 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
                         pk.Rjmap = fr.gpuRjmap ; pk.Rimap = fr.gpuRimap ;
                         pk.cld = cld ;
                         pk.pn = (int32_t) std::max<int64_t> (fr.pn, front_pitch (fronts [fr.pids])) ;
-                        pk.cistart = ci ; pk.ciend = std::min (ci + QR_PACK_TILE, fr.cm) ;
+                        pk.cistart = ci ; pk.ciend = ciend ;
                         pk.cjstart = cj ; pk.cjend = std::min (cj + QR_PACK_TILE, fr.cn) ;
                         st.round = round ; st.slot = 8 ; st.vt = -1 ; st.nblk = 1 ;
-                        for (int c = 0 ; c < QR_NCLASS ; c++) st.dep [c] = last [c] ;
+                        for (int c = 0 ; c < QR_NCLASS ; c++) st.dep [c] = dep [c] ;
                         st.wait_ctr = (int32_t) f ; st.signal_ctr = (int32_t) fr.pids ;
                         {
                             // entries of the tile on or above the diagonal: 8 read + 8 written, plus the map ints
@@ -1195,10 +1272,21 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
                         }
                         plan.tasks.push_back (st) ;
                     }
+                    if (by_rows)
+                    {
+                        EvNode nd ;
+                        nd.ev.min_row = fr.cpuRimap [ci] ; nd.ev.round = round ;
+                        nd.next = ev_head [fr.pids] ;
+                        ev_head [fr.pids] = (int64_t) evpool.size ( ) ;
+                        evpool.push_back (nd) ;
+                    }
                 }
-                int32_t &pl = in_last [fr.pids*QR_NCLASS + 2] ;
-                pl = std::max (pl, round) ;
-                done_last [f*QR_NCLASS + 2] = std::max (done_last [f*QR_NCLASS + 2], round) ;
+                if (!by_rows)
+                {
+                    int32_t &pl = in_last [fr.pids*QR_NCLASS + 2] ;
+                    pl = std::max (pl, round_max) ;
+                }
+                done_last [f*QR_NCLASS + 2] = std::max (done_last [f*QR_NCLASS + 2], round_max) ;
             }
         }
 

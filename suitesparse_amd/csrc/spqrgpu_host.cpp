@@ -251,11 +251,49 @@ static void release_numeric_cache (spqr_amd_symbolic::NumericCache *c)
 // symbolic object and device.  Runs the restated spqrgpu_buildAssemblyMaps with the position of
 // each entry in place of its value, which gives the permutation from the caller's Ax to packed S.
 // Returns 0, 1 (out of memory) or 2 (device error).
+// 64-bit fingerprint of a column pattern.  Eight interleaved multiply-xor chains (one chain is bound
+// by the latency of its multiply, 9 ms for the 10 M entries of a 1024 x 1024 grid), on up to four
+// threads for large patterns; the position of every entry enters through the chain it falls into and
+// the order inside the chain.
+static uint64_t hash_span (const int64_t *x, Long len, uint64_t seed)
+{
+    const uint64_t M = 0xff51afd7ed558ccdull ;
+    uint64_t h [8] ;
+    for (int l = 0 ; l < 8 ; l++) h [l] = seed + 0x9E3779B97F4A7C15ull * (uint64_t) (l + 1) ;
+    Long k = 0 ;
+    for ( ; k + 8 <= len ; k += 8)
+        for (int l = 0 ; l < 8 ; l++) { h [l] = (h [l] ^ (uint64_t) x [k + l]) * M ; h [l] ^= h [l] >> 29 ; }
+    for ( ; k < len ; k++) { h [k & 7] = (h [k & 7] ^ (uint64_t) x [k]) * M ; h [k & 7] ^= h [k & 7] >> 29 ; }
+    uint64_t r = seed ^ (uint64_t) len ;
+    for (int l = 0 ; l < 8 ; l++) { r = (r ^ h [l]) * M ; r ^= r >> 32 ; }
+    return r ;
+}
+
 static uint64_t pattern_fingerprint (const int64_t *Ap, const int64_t *Ai, Long n, Long anz)
 {
-    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t) n ;
-    for (Long k = 0 ; k <= n ; k++) { h = (h ^ (uint64_t) Ap [k]) * 0xff51afd7ed558ccdull ; h ^= h >> 32 ; }
-    for (Long k = 0 ; k < anz ; k++) { h = (h ^ (uint64_t) Ai [k]) * 0xff51afd7ed558ccdull ; h ^= h >> 32 ; }
+    uint64_t h = hash_span (Ap, n + 1, 0x243F6A8885A308D3ull ^ (uint64_t) n) ;
+    const int nth = (anz >= ((Long) 1 << 20)) ? 4 : 1 ;
+    uint64_t part [4] = {0, 0, 0, 0} ;
+    if (nth == 1) part [0] = hash_span (Ai, anz, 1) ;
+    else
+    {
+        std::thread th [3] ;
+        const Long chunk = (anz + nth - 1) / nth ;
+        int started = 0 ;
+        try
+        {
+            for (int t = 1 ; t < nth ; t++)
+            {
+                th [t-1] = std::thread ([=, &part] ( ) { part [t] = hash_span (Ai + t * chunk, std::min (chunk, anz - t * chunk), (uint64_t) t + 1) ; }) ;
+                started = t ;
+            }
+        }
+        catch (...) { }
+        part [0] = hash_span (Ai, chunk, 1) ;
+        for (int t = 1 ; t <= started ; t++) th [t-1].join ( ) ;
+        for (int t = started + 1 ; t < nth ; t++) part [t] = hash_span (Ai + t * chunk, std::min (chunk, anz - t * chunk), (uint64_t) t + 1) ;
+    }
+    for (int t = 0 ; t < nth ; t++) { h = (h ^ part [t]) * 0xff51afd7ed558ccdull ; h ^= h >> 32 ; }
     return h ;
 }
 
@@ -825,6 +863,8 @@ static int factorize_impl
                     fr.pn = (int32_t) pitch [pid] ;
                     fr.gpuRjmap = rjmap_base + S->RjmapOffsets [f] ;
                     fr.gpuRimap = (int32_t *) NC.d_Rimap + S->RimapOffsets [f] ;
+                    // (with dead columns the rows of a parent are permuted on the device only)
+                    fr.cpuRimap = rp ? NULL : NC.Rimap.data ( ) + S->RimapOffsets [f] ;
                     fr.gpuC = fr.gpuF + frank * pitch [f] + fp ;
                 }
                 else if (pid < nf)
@@ -848,6 +888,7 @@ static int factorize_impl
                     ch.is_sparse = 1 ; ch.push_only = 1 ;
                     ch.pn = (int32_t) pitch [f] ; ch.cm = (int32_t) ccm ; ch.cn = (int32_t) ccn ;
                     ch.gpuRimap = (int32_t *) NC.d_Rimap + S->RimapOffsets [c] ;
+                    ch.cpuRimap = rp ? NULL : NC.Rimap.data ( ) + S->RimapOffsets [c] ;
                     ch.gpuRjmap = rjmap_base + S->RjmapOffsets [c] ;
                     const bool in_place = child_in_place (c) ;
                     if (in_place && external)

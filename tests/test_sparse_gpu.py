@@ -232,6 +232,24 @@ def test_pageable_r_stack_with_stages_copies_beside_the_next_stage(monkeypatch):
     assert (r1.R != one.R).nnz == 0 or np.abs((r1.R - one.R)).max() <= 1e-13 * np.abs(one.R).max()
 
 
+@pytest.mark.parametrize("grid,leaf,mem", [((48, 48), 4, 2**34), ((12, 12, 12), 2, 2**34), ((48, 48), 4, 20_000_000)])
+def test_contribution_blocks_sent_row_block_by_row_block_change_nothing(monkeypatch, grid, leaf, mem):
+    """With the host copy of the row map the engine sends a child's rows to the parent as they become
+    final and starts the parent's panels early.  Same arithmetic in the same order: R must be
+    bit-identical to the factorization where every parent waits for its whole children, in fewer
+    launches (more tasks share a round)."""
+    A = problems.stacked_ls(grid)
+    Q = problems.nested_dissection(grid, leaf=leaf)
+    # (a schedule is kept per symbolic object: two objects, two schedules)
+    monkeypatch.setenv("GPUQR_NO_PIPELINE", "1")
+    whole = spqr.factorize(spqr.analyze(A, Q, relax=20, gpuMemorySize=mem), A)
+    monkeypatch.delenv("GPUQR_NO_PIPELINE")
+    early = spqr.factorize(spqr.analyze(A, Q, relax=20, gpuMemorySize=mem), A)
+    assert early.rank == whole.rank == A.shape[1]
+    assert (early.R != whole.R).nnz == 0
+    assert early.gpuNumKernelLaunches < whole.gpuNumKernelLaunches
+
+
 @pytest.mark.parametrize("grid,leaf,mem,mode", [((30, 30), 4, 2**34, 0), ((10, 10, 10), 2, 2**34, 0),
                                                 ((30, 30), 4, 2**22, 0), ((30, 30), 4, 2**34, 1)])
 def test_r_packed_inside_the_engine_equals_r_packed_afterwards(monkeypatch, grid, leaf, mem, mode):
