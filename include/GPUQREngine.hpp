@@ -64,10 +64,11 @@ public:
     int cm, cn, csize, pn, pc, lastCiStart, lastCjStart ;
     int *gpuRjmap, *gpuRimap ;
     double *gpuC, *gpuP ;
+    const int *cpuRimap ;       // extension (not in the reference's class): host copy of gpuRimap, may stay NULL
     SparseMeta ( ) : fp (0), nc (0), isStaged (false), pushOnly (false), isSparse (false),
         lastSIndex (0), cpuS (NULL), gpuS (NULL), Scount (0), cm (0), cn (0), csize (0), pn (0),
         pc (0), lastCiStart (0), lastCjStart (0), gpuRjmap (NULL), gpuRimap (NULL), gpuC (NULL),
-        gpuP (NULL) { }
+        gpuP (NULL), cpuRimap (NULL) { }
 } ;
 
 class Front
@@ -118,6 +119,7 @@ namespace gpuqr_shim
         c.gpuS = reinterpret_cast<const gpuqr_sentry *> (m.gpuS) ; c.Scount = m.Scount ;
         c.cm = m.cm ; c.cn = m.cn ; c.pn = m.pn ;
         c.gpuRjmap = m.gpuRjmap ; c.gpuRimap = m.gpuRimap ; c.gpuC = m.gpuC ;
+        c.cpuRimap = m.cpuRimap ;
     }
     inline QREngineResultCode run (size_t mem, Front *fronts, Int n, bool dense,
         const Int *Parent, const Int *Childp, const Int *Child, QREngineStats *stats)

@@ -53,15 +53,25 @@ def counters(db_path, out_md):
         agg.setdefault(k, {})[counter] = tot
         cnt[k] = n
     names = sorted({c for v in agg.values() for c in v})
+    # The SQ counters come as one value per shader engine (8 XCDs x 4 = 32 per launch on an MI355X).
+    # SQ_BUSY_CYCLES / 32 is then the launch's duration in shader cycles, and the matrix pipes of the
+    # chip's 1024 SIMDs could have been busy for 1024 times that many cycles.  One MOPS_F64 unit is
+    # 512 flops (a v_mfma_f64_16x16x4_f64 = 2048 flops = 4 units = 64 busy cycles).
+    inst, simds = 32, 1024
     with open(out_md, "w") as f:
-        f.write("| kernel | launches | " + " | ".join(names) + " | MFMA busy / SQ busy |\n")
-        f.write("|---|---|" + "---|" * (len(names) + 1) + "\n")
+        f.write("| kernel | counter rows | " + " | ".join(names) + " | MFMA busy share of SIMD cycles | issued F64 MFMA TFLOP per launch-second |\n")
+        f.write("|---|---|" + "---|" * (len(names) + 2) + "\n")
         for k in sorted(agg, key=lambda k: -agg[k].get("SQ_BUSY_CYCLES", 0)):
             v = agg[k]
-            ratio = ""
+            ratio = rate = ""
             if v.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
-                ratio = "%.3f" % (v["SQ_VALU_MFMA_BUSY_CYCLES"] / v["SQ_BUSY_CYCLES"])
-            f.write("| %s | %d | " % (k, cnt[k]) + " | ".join("%.4g" % v.get(c, 0) for c in names) + " | %s |\n" % ratio)
+                ratio = "%.3f" % (v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["SQ_BUSY_CYCLES"] / inst * simds))
+            if v.get("SQ_BUSY_CYCLES") and "SQ_INSTS_VALU_MFMA_MOPS_F64" in v:
+                # flops per shader cycle of launch time; times the clock gives the rate
+                rate = "%.1f flop/cycle" % (v["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512 / (v["SQ_BUSY_CYCLES"] / inst))
+            f.write("| %s | %d | " % (k, cnt[k]) + " | ".join("%.4g" % v.get(c, 0) for c in names) + " | %s | %s |\n" % (ratio, rate))
+        f.write("\nCounter rows = launches x %d shader engines.  MFMA busy share = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES / %d x %d SIMDs); "
+                "the last column is SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flops per shader cycle of launch time (chip peak: 32768 flop/cycle).\n" % (inst, inst, simds))
 
 
 def pmc(fetch_db, write_db, out_json, out_md, tag="dense", command=None):

@@ -203,3 +203,33 @@ def test_repeated_device_batches_reuse_the_schedule_and_follow_the_values():
             assert r_rel_diff(R, Rref) <= 1e-12
         if trial == 1:
             assert ss.GPUQREngine(0, other, 1) == ss.QRENGINE_SUCCESS
+
+
+@pytest.mark.parametrize("switch", ["GPUQR_LOOKAHEAD_TILES=2", "GPUQR_LOOKAHEAD_TILES=8", "GPUQR_NO_PIPELINE=1",
+                                    "GPUQR_SPLIT_TIERS=1", "GPUQR_RIDE_BELOW=0", "GPUQR_SMALL_ON=0"])
+def test_schedule_switches_in_a_fresh_process(tmp_path, switch):
+    """The schedule switches change which tasks share a launch and which stream runs them, never the
+    arithmetic of a task: a process started with one of them set must produce bit-identical R for a
+    dense batch and a sparse problem (the look-ahead splits an update by columns, and columns are
+    updated independently of each other).  The switches are read once per process, hence the child."""
+    import os
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import knob_worker
+    ref = knob_worker.run()
+    out = str(tmp_path / "r.npz")
+    name, value = switch.split("=")
+    with open(str(tmp_path / "out.txt"), "w") as fo:
+        rc = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "knob_worker.py"), out],
+                            stdout=fo, stderr=subprocess.STDOUT, env=dict(os.environ, **{name: value}), timeout=150).returncode
+    assert rc == 0, open(str(tmp_path / "out.txt")).read()[-3000:]
+    z = np.load(out)
+    for k in ref:
+        if k.endswith("launches"):
+            continue
+        assert z[k].shape == ref[k].shape and np.array_equal(z[k], ref[k]), k
+    if name == "GPUQR_LOOKAHEAD_TILES":
+        assert int(z["dense_launches"]) > int(ref["dense_launches"])     # the switch did take effect
+    if name == "GPUQR_NO_PIPELINE":
+        assert int(z["sp_launches"]) > int(ref["sp_launches"])
