@@ -8,15 +8,19 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # with 44,000 launches queued behind each other the profiler's process segfaults inside a launch (the
 # same command runs through without it); waiting for the device every 4096 launches avoids that
-export GPUQR_SYNC_EVERY=4096
+export GPUQR_SYNC_EVERY=${GPUQR_SYNC_EVERY:-4096}
+PASSES=${1:-kt,pmc}
 B="$GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --extras none --no-cpu-baseline"
 S="$GRAFT_REPO_ROOT/scripts/rocpd_summary.py"
 db () { find "$1" -name '*_results.db' | head -1 ; }
 rm -rf /tmp/p_kt /tmp/p_f /tmp/p_w /tmp/p_m
+if [[ $PASSES == *kt* ]]; then
 echo "== kernel trace" ; date
 timeout -s KILL 500 rocprofv3 --kernel-trace --stats -d /tmp/p_kt -- python3 $B > "$OUT/kt_line.json" 2> "$OUT/kt.err"
 python3 $S stats "$(db /tmp/p_kt)" "$OUT/kernel_stats.csv"
 python3 $S gaps "$(db /tmp/p_kt)" > "$OUT/queue_gaps.txt"
+fi
+[[ $PASSES == *pmc* ]] || exit 0
 echo "== FETCH_SIZE" ; date
 timeout -s KILL 700 rocprofv3 --pmc FETCH_SIZE -d /tmp/p_f -- python3 $B > "$OUT/f_line.json" 2> "$OUT/f.err"
 echo "== WRITE_SIZE" ; date
