@@ -60,6 +60,35 @@ def test_sparse_qr_one_stage(name, A, Q, relax):
     assert np.linalg.norm(R.T @ R - G, 1) / np.linalg.norm(G, 1) <= 1e-12
 
 
+@pytest.mark.parametrize("shape,leaf", [((512, 512), 8), ((56, 56, 56), 8)])
+def test_large_grids_by_size_independent_properties(shape, leaf):
+    """Sizes at which no dense comparison is possible (fronts of thousands of columns, many rounds of
+    row-block hand-overs, R of 10^7..10^8 entries): R'R y = (AQ)'(AQ) y for random y, which pins every
+    entry of R'R without forming it; ||R y|| = ||A Q y||; R upper triangular with the symbolic pattern;
+    the same R from a second factorization that replays the schedule."""
+    A = problems.stacked_ls(shape)
+    sym = spqr.analyze(A, problems.nested_dissection(shape, leaf=leaf), relax=20, gpuMemorySize=2**36)
+    assert sym.numStages == 1
+    res = spqr.factorize(sym, A)
+    n = sym.n
+    assert res.rank == n
+    R = res.R.tocsr()
+    assert R.shape == (n, n) and R.nnz == sym.rnz
+    coo = R.tocoo()
+    assert (coo.row <= coo.col).all()
+    assert (R.diagonal()[:-1] > 0).all()
+    AQ = A[:, sym.Qfill[:n]].tocsr()
+    rng = np.random.default_rng(9)
+    for _ in range(3):
+        y = rng.standard_normal(n)
+        Ry, Ay = R @ y, AQ @ y
+        assert abs(np.linalg.norm(Ry) - np.linalg.norm(Ay)) <= 1e-12 * np.linalg.norm(Ay)
+        u, v = R.T @ Ry, AQ.T @ Ay
+        assert np.linalg.norm(u - v) <= 1e-12 * np.linalg.norm(v)
+    again = spqr.factorize(sym, A)
+    assert (again.R != res.R).nnz == 0
+
+
 @pytest.mark.parametrize("name,A,Q", CASES[:4], ids=[c[0] for c in CASES[:4]])
 @pytest.mark.parametrize("mem", [0, 10_700_000, 11_200_000])
 @pytest.mark.parametrize("host_limbo", [False, True])
