@@ -38,7 +38,7 @@ PEAK_FP64_MFMA_TFLOPS = 78.6      # MI355X FP64 matrix peak = half the FP32-inpu
 PEAK_HBM_GBS = 8000.0
 KERNEL_NAMES = ["k_factorize<4, 8>", "k_factorize<4, 16>", "k_factorize<8, 16>", "k_factorize<16, 16>",
                 "k_apply<2>", "k_apply<4>", "k_apply<8>", "k_apply<16>", "k_assemble",
-                "k_factorize_all", "k_apply_small", "k_apply_all"]
+                "k_factorize_all", "k_apply_small", "k_apply_all", "k_round_all"]
 HEADLINE = "sparse3d:96"
 DECLARED_DEVICE_MEMORY = 200 * 2**30
 T_START = time.perf_counter()

@@ -1,22 +1,17 @@
-# A/B runs of schedule knobs: prints step / kernel ms per setting.
+# tests, the child-after-big probe, and A/B runs of the assembly-join threshold
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
 run () { # tag workload env...
   tag=$1; wl=$2; shift 2
-  env "$@" timeout -k 10 300 python bench.py --workload $wl --steps 4 --warmup 2 --extras none --no-cpu-baseline > $O/ab_$tag.json 2> $O/ab_$tag.err || exit 1
+  env "$@" timeout -k 10 300 python bench.py --workload $wl --steps 5 --warmup 2 --extras none --no-cpu-baseline > $O/ab_$tag.json 2> $O/ab_$tag.err || exit 1
   python3 -c "import json;d=json.loads(open('$O/ab_$tag.json').read().strip().splitlines()[-1]);print('$tag',round(d['ms_per_step'],1),round(d['kernel_ms_per_step'],1),d['launches_per_step'])"
 }
-for wl in sparse3d:64 sparse2d:1024; do
-run base_$wl $wl A=1 &&
-run wide768_$wl $wl GPUQR_WIDE_ABOVE=768 &&
-run wide3072_$wl $wl GPUQR_WIDE_ABOVE=3072 &&
-run wide0_$wl $wl GPUQR_WIDE_ABOVE=0 &&
-run narrow64_$wl $wl GPUQR_NARROW_BELOW=64 &&
-run narrow256_$wl $wl GPUQR_NARROW_BELOW=256 &&
-run narrow512_$wl $wl GPUQR_NARROW_BELOW=512 &&
-run ride0_$wl $wl GPUQR_RIDE_BELOW=0 &&
-run ride1024_$wl $wl GPUQR_RIDE_BELOW=1024 &&
-run ride2048_$wl $wl GPUQR_RIDE_BELOW=2048 &&
-run small1_$wl $wl GPUQR_SMALL_ON=1 &&
-run small0_$wl $wl GPUQR_SMALL_ON=0 || exit 1
+timeout -k 10 200 python -u scripts/dbg/child_after_big.py 64x64x64 2>&1 | grep -v "amdgpu\|^  \|Traceback\|RuntimeError"
+timeout -k 10 600 python -u -m pytest tests/test_sparse_gpu.py tests/test_edges_gpu.py -m gpu -x -q --timeout 120 --timeout-method thread > $O/join_tests.log 2>&1 || { tail -20 $O/join_tests.log; exit 1; }
+tail -2 $O/join_tests.log
+for wl in sparse2d:1024 sparse3d:64; do
+run join0_$wl $wl GPUQR_ASM_JOIN_BELOW=0 &&
+run join256_$wl $wl GPUQR_ASM_JOIN_BELOW=256 &&
+run join1024_$wl $wl GPUQR_ASM_JOIN_BELOW=1024 &&
+run join8192_$wl $wl GPUQR_ASM_JOIN_BELOW=8192 || exit 1
 done

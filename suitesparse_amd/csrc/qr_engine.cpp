@@ -45,7 +45,7 @@ extern "C" hipError_t qr_kernels_init (void) ;
 extern "C" hipError_t qr_launch_persistent (const QrTask *d_tasks, const QrQueueRef *d_refs, int nrefs,
     int *d_counters, int nworkgroups, hipStream_t stream) ;
 
-#define QR_NKERNELS 12     // 0..8 one per task kind and tier; 9..11 the launches that merge tiers
+#define QR_NKERNELS 13     // 0..8 one per task kind and tier; 9..12 the launches that merge tiers (12: and assembly)
 
 // -----------------------------------------------------------------------------
 // allocator hooks
@@ -561,6 +561,10 @@ struct LaunchPlan
     int64_t flops = 0 ;
 } ;
 
+// bound on the launches left queued at a time: a checkpoint every QR_CK_EVERY launches, QR_CK_SLOTS of them in flight
+#define QR_CK_EVERY 512
+#define QR_CK_SLOTS 5
+
 struct DeviceCache
 {
     bool ready = false ;
@@ -569,7 +573,8 @@ struct DeviceCache
     int64_t plan_nf = 0 ;
     hipStream_t sCompute = NULL, sApply = NULL, sCopy = NULL ;
     hipEvent_t evStart = NULL, evStop = NULL ;
-    std::vector<hipEvent_t> evPool ;        // untimed events, reused by every call
+    std::vector<hipEvent_t> evPool [3] ;    // untimed events per task class, reused by every call
+    hipEvent_t evCheck [QR_CK_SLOTS][2] = {} ;  // checkpoints of the two compute streams that bound the queued launches
     void *d_tasks = NULL, *d_refs = NULL, *d_vt = NULL, *h_stage = NULL, *d_counters = NULL, *d_pack = NULL ;
     size_t cap_tasks = 0, cap_refs = 0, cap_vt = 0, cap_stage = 0, cap_counters = 0, cap_pack = 0 ;
     int num_cus = 0 ;
@@ -587,23 +592,33 @@ struct DeviceCache
         *cap = want ;
         return hipSuccess ;
     }
-    // k-th untimed event of the pool (created on first use)
-    hipEvent_t pooled_event (size_t k)
+    // k-th untimed event of class c's pool (created on first use).  Each class has a ring of events: the
+    // k-th event of a call is slot k mod ring, so an old slot is recorded again by a later launch of the
+    // same class, on the same stream.  A wait on a reused slot then waits for a later launch of a stream
+    // that runs in order: never too little.  Why a ring: a process that held more than about 4,500
+    // recorded events kept every new process on the machine from initialising the device (they died in
+    // their first copy); 3 x 1024 stays clear of that.
+    hipEvent_t pooled_event (int c, size_t k)
     {
-        while (evPool.size ( ) <= k)
+        static size_t ring = 0 ;
+        if (ring == 0) { const char *e = getenv ("GPUQR_EVENT_RING") ; ring = e ? (size_t) std::max (16, atoi (e)) : 1024 ; }
+        std::vector<hipEvent_t> &pool = evPool [c] ;
+        k %= ring ;
+        while (pool.size ( ) <= k)
         {
             hipEvent_t ev = NULL ;
             if (hipEventCreateWithFlags (&ev, hipEventDisableTiming) != hipSuccess) return NULL ;
-            evPool.push_back (ev) ;
+            pool.push_back (ev) ;
         }
-        return evPool [k] ;
+        return pool [k] ;
     }
     void release ( )
     {
         if (sCompute) (void) hipStreamDestroy (sCompute) ;
         if (sApply) (void) hipStreamDestroy (sApply) ;
         if (sCopy) (void) hipStreamDestroy (sCopy) ;
-        for (size_t i = 0 ; i < evPool.size ( ) ; i++) (void) hipEventDestroy (evPool [i]) ;
+        for (int c = 0 ; c < 3 ; c++) { for (size_t i = 0 ; i < evPool [c].size ( ) ; i++) (void) hipEventDestroy (evPool [c][i]) ; evPool [c].clear ( ) ; }
+        for (int i = 0 ; i < QR_CK_SLOTS ; i++) for (int k = 0 ; k < 2 ; k++) { if (evCheck [i][k]) (void) hipEventDestroy (evCheck [i][k]) ; evCheck [i][k] = NULL ; }
         if (evStart) (void) hipEventDestroy (evStart) ;
         if (evStop) (void) hipEventDestroy (evStop) ;
         if (d_tasks) (void) hipFree (d_tasks) ;
@@ -790,7 +805,7 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
     hvec<int64_t> evProfBucket ;      // per profiled launch: first bucket, workgroups, kernel id
     hvec<int64_t> evProfN ;
     hvec<int> evProfKid ;
-    int64_t launches = 0, synced_at = 0 ;
+    int64_t launches = 0, synced_at = 0, ck_at = 0, ck_n = 0 ;
     float ms = 0 ;
     try
     {
@@ -834,7 +849,8 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
             hipStream_t cstream [QR_NCLASS] = {sCompute, sApply, small_on ? sApply : sCompute} ;
             HIP_TRY (hipEventRecord (evStart, sCompute)) ;
             for (int c = 1 ; c < QR_NCLASS ; c++) HIP_TRY (hipStreamWaitEvent (cstream [c], evStart, 0)) ;    // the task upload
-            size_t pi = 0, nev = 0 ;
+            size_t pi = 0 ;
+            size_t nev [QR_NCLASS] = {0, 0, 0} ;
             // R blocks packed for the caller: fronts grouped by the rounds in which they become final
             static int rgroup = 0 ;
             if (rgroup == 0) { const char *e = getenv ("GPUQR_RCOPY_GROUP") ; rgroup = e ? std::max (1, atoi (e)) : 256 ; }
@@ -844,8 +860,12 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
             // evAt [c][r]: event recorded after the last launch of class c in the latest round <= r that had one
             hvec<hipEvent_t> evAt [QR_NCLASS] ;
             for (int c = 0 ; c < QR_NCLASS ; c++) evAt [c].assign ((size_t) nrounds, (hipEvent_t) NULL) ;
-            hipEvent_t waited [QR_NCLASS][QR_NCLASS] ;
-            for (int x = 0 ; x < QR_NCLASS ; x++) for (int y = 0 ; y < QR_NCLASS ; y++) waited [x][y] = NULL ;
+            // evRound [c][r]: the round in which evAt [c][r] was recorded (-1: none).  Events come from a ring
+            // and are recorded again later, so "already waited for" is decided by rounds, not by handles.
+            hvec<int32_t> evRound [QR_NCLASS] ;
+            for (int c = 0 ; c < QR_NCLASS ; c++) evRound [c].assign ((size_t) nrounds, -1) ;
+            int32_t wround [QR_NCLASS][QR_NCLASS] ;    // class x's stream has waited for class y's launches up to this round
+            for (int x = 0 ; x < QR_NCLASS ; x++) for (int y = 0 ; y < QR_NCLASS ; y++) wround [x][y] = -1 ;
             static const int slot_order [QR_NSLOTS] = {0, 1, 2, 3, 9, 10, 11, 12, 7, 4, 5, 6, 8} ;
             // Row tiers that are neighbours in the slot order and share a class go out as one launch
             // (slots 0..3: all panel tiers; 4..6: the small update tiers), unless the per-kernel profile
@@ -853,6 +873,8 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
             const bool merge_tiers = getenv ("GPUQR_SPLIT_TIERS") == NULL ;
             static int ride_below = -1 ;
             if (ride_below < 0) { const char *e = getenv ("GPUQR_RIDE_BELOW") ; ride_below = e ? atoi (e) : 512 ; }
+            static int asm_join = -1 ;      // assembly launches below this many workgroups join the round's updates
+            if (asm_join < 0) { const char *e = getenv ("GPUQR_ASM_JOIN_BELOW") ; asm_join = e ? atoi (e) : 1024 ; }
             for (int32_t r = 0 ; r < nrounds ; r++)
             {
                 bool launched [QR_NCLASS] = {false, false, false} ;
@@ -885,15 +907,30 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
                     const int64_t b4 = (int64_t) r * QR_NSLOTS + 4, b7 = (int64_t) r * QR_NSLOTS + 7 ;
                     const bool ride = merge_tiers && ride_below > 0 && rptr [b7+1] > rptr [b7] && rptr [b7] > rptr [b4]
                         && rptr [b7+1] - rptr [b7] < ride_below ;
+                    // A round's few assembly workgroups join its update launch when they follow it in the
+                    // workgroup list (slot 8 comes right after slots 4..7) and on its stream anyway.
+                    const int64_t b8 = (int64_t) r * QR_NSLOTS + 8 ;
+                    const int64_t n8 = rptr [b8+1] - rptr [b8] ;
+                    const bool asm_small = merge_tiers && asm_join > 0 && n8 > 0 && n8 < asm_join ;
+                    const bool asm_rides = asm_small && ride && cstream [2] == cstream [1] ;
+                    const bool asm_with_small = asm_small && !ride && rptr [b7+1] == rptr [b7] && rptr [b7] > rptr [b4] ;
                     if (ride && slot == 4) continue ;           // launched with slot 7
+                    if ((asm_rides || asm_with_small) && slot == 8) continue ;      // launched with the updates
                     if (ride && slot == 7)
                     {
                         rode = true ;
                         b = b4 ;
-                        n = rptr [b7+1] - rptr [b4] ;
-                        kid = 11 ;
-                        for (int64_t bb = b4 ; bb <= b7 ; bb++)
+                        const int64_t bend = asm_rides ? b8 : b7 ;
+                        n = rptr [bend+1] - rptr [b4] ;
+                        kid = asm_rides ? 12 : 11 ;
+                        for (int64_t bb = b4 ; bb <= bend ; bb++)
                             for (int c = 0 ; c < QR_NCLASS ; c++) dmerged [c] = std::max (dmerged [c], bdep [bb*QR_NCLASS + c]) ;
+                    }
+                    if (asm_with_small && slot == 4)
+                    {
+                        n = rptr [b8+1] - rptr [b4] ;
+                        kid = 12 ;
+                        for (int c = 0 ; c < QR_NCLASS ; c++) dmerged [c] = std::max (dmerged [c], bdep [b8*QR_NCLASS + c]) ;
                     }
                     if (n <= 0) continue ;
                     RoundLaunch &rl = rls [nrl++] ;
@@ -918,9 +955,9 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
                         const int32_t d = dmerged [y] ;
                         if (y == x || d < 0 || cstream [y] == st) continue ;
                         hipEvent_t ev = evAt [y][d] ;
-                        if (ev == NULL || ev == waited [x][y]) continue ;
+                        if (ev == NULL || evRound [y][d] <= wround [x][y]) continue ;
                         HIP_TRY (hipStreamWaitEvent (st, ev, 0)) ;
-                        waited [x][y] = ev ;
+                        wround [x][y] = evRound [y][d] ;
                     }
                     if (g_profile_on)
                     {
@@ -932,7 +969,7 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
                     }
                     else if (i == last_of [x])
                     {
-                        hipEvent_t ev = dc->pooled_event (nev++) ;
+                        hipEvent_t ev = dc->pooled_event (x, nev [x]++) ;
                         if (!ev) { code = GPUQR_GPUERROR ; goto cleanup ; }
                         HIP_TRY (qr_launch_tasks_ev (kid, d_tasks, d_refs + rptr [b], (int) n, st, ev)) ;
                         ev_of [x] = ev ;
@@ -952,15 +989,19 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
                         if (ev == NULL)
                         {
                             // (profiled call: its launches carry timing events, so this one is recorded apart)
-                            ev = dc->pooled_event (nev++) ;
+                            ev = dc->pooled_event (c, nev [c]++) ;
                             if (!ev) { code = GPUQR_GPUERROR ; goto cleanup ; }
                             HIP_TRY (hipEventRecord (ev, cstream [c])) ;
                         }
-                        evAt [c][r] = ev ;
+                        evAt [c][r] = ev ; evRound [c][r] = r ;
                         // a class that shares the stream is covered by the same event
-                        for (int c2 = 0 ; c2 < c ; c2++) if (cstream [c2] == cstream [c]) evAt [c2][r] = ev ;
+                        for (int c2 = 0 ; c2 < c ; c2++) if (cstream [c2] == cstream [c]) { evAt [c2][r] = ev ; evRound [c2][r] = r ; }
                     }
-                    else evAt [c][r] = (r > 0) ? evAt [c][r-1] : (hipEvent_t) NULL ;
+                    else
+                    {
+                        evAt [c][r] = (r > 0) ? evAt [c][r-1] : (hipEvent_t) NULL ;
+                        evRound [c][r] = (r > 0) ? evRound [c][r-1] : -1 ;
+                    }
                 }
                 if (rode && cstream [2] != cstream [1] && launched [2])
                 {
@@ -969,17 +1010,17 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
                     // launch and a fresh event is recorded behind that wait, so whoever waits for class 2
                     // of this round waits for both.
                     HIP_TRY (hipStreamWaitEvent (cstream [2], evAt [1][r], 0)) ;
-                    hipEvent_t ev = dc->pooled_event (nev++) ;
+                    hipEvent_t ev = dc->pooled_event (2, nev [2]++) ;
                     if (!ev) { code = GPUQR_GPUERROR ; goto cleanup ; }
                     HIP_TRY (hipEventRecord (ev, cstream [2])) ;
-                    evAt [2][r] = ev ;
-                    for (int c2 = 0 ; c2 < 2 ; c2++) if (cstream [c2] == cstream [2]) evAt [c2][r] = ev ;
+                    evAt [2][r] = ev ; evRound [2][r] = r ;
+                    for (int c2 = 0 ; c2 < 2 ; c2++) if (cstream [c2] == cstream [2]) { evAt [c2][r] = ev ; evRound [c2][r] = r ; }
                 }
                 else if (rode)
                 {
                     // only the bulk stream ran class-2 work this round; the class-2 stream stays in order behind it
                     if (cstream [2] != cstream [1]) HIP_TRY (hipStreamWaitEvent (cstream [2], evAt [1][r], 0)) ;
-                    evAt [2][r] = evAt [1][r] ;
+                    evAt [2][r] = evAt [1][r] ; evRound [2][r] = evRound [1][r] ;
                 }
                 if (pi < pull_order.size ( ) && std::min (final_round (pull_order [pi]), nrounds - 1) <= r)
                 {
@@ -993,8 +1034,31 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
                         HIP_TRY (pull_rows (fr, nrows, sCopy)) ;
                     }
                 }
-                // GPUQR_SYNC_EVERY=n: wait for the device every n launches.  Off by default; a profiler
-                // that keeps a record per launch in flight was seen to crash with 40,000 launches queued.
+                // No more than about 2,500 launches are left queued at any time.  With some 4,500 or more
+                // launches of one process waiting in its queues, every process that initialised the device
+                // meanwhile died in its first copy (seen with 5,963 queued launches, not with 4,444; a wait
+                // every 3,000 cured it), and a profiler attached to the process crashed.  Every 512 launches
+                // both compute streams record a checkpoint; before a checkpoint slot is used again, five
+                // checkpoints later, the host waits for it.  The device still has 2,000 launches queued then.
+                if (launches - ck_at >= QR_CK_EVERY)
+                {
+                    hipEvent_t *slot = dc->evCheck [ck_n % QR_CK_SLOTS] ;
+                    if (!slot [0])
+                    {
+                        HIP_TRY (hipEventCreateWithFlags (&slot [0], hipEventDisableTiming)) ;
+                        HIP_TRY (hipEventCreateWithFlags (&slot [1], hipEventDisableTiming)) ;
+                    }
+                    else if (ck_n >= QR_CK_SLOTS)
+                    {
+                        HIP_TRY (hipEventSynchronize (slot [0])) ;
+                        HIP_TRY (hipEventSynchronize (slot [1])) ;
+                    }
+                    HIP_TRY (hipEventRecord (slot [0], sCompute)) ;
+                    HIP_TRY (hipEventRecord (slot [1], sApply)) ;
+                    ck_n++ ;
+                    ck_at = launches ;
+                }
+                // GPUQR_SYNC_EVERY=n: wait for the device every n launches (off; for experiments).
                 static int sync_every = -1 ;
                 if (sync_every < 0) { const char *e = getenv ("GPUQR_SYNC_EVERY") ; sync_every = e ? atoi (e) : 0 ; }
                 if (sync_every > 0 && launches - synced_at >= sync_every)
@@ -1745,6 +1809,7 @@ extern "C" int gpuqr_factor_sparse_noalloc (gpuqr_front *fronts, int64_t nf, gpu
                     if (n <= 0) continue ;
                     HIP_TRY (qr_launch_tasks (slot_kernel (slot), d_tasks, d_refs + sc.rptr [b], (int) n, stream)) ;
                     launches++ ;
+                    if ((launches & 2047) == 0) HIP_TRY (hipStreamSynchronize (stream)) ;      // bound on the queued launches
                 }
             }
             HIP_TRY (hipEventRecord (dc->evStop, stream)) ;
@@ -1903,6 +1968,7 @@ extern "C" int gpuqr_factor_sparse_keep (gpuqr_front *fronts, int64_t nf, gpuqr_
                     if (n <= 0) continue ;
                     ok = qr_launch_tasks (slot_kernel (slot), (const QrTask *) rp->d_tasks, (const QrRef *) d_refs_all + sc.rptr [b], (int) n, stream) == hipSuccess ;
                     launches++ ;
+                    if (ok && (launches & 2047) == 0) ok = hipStreamSynchronize (stream) == hipSuccess ;   // bound on the queued launches
                 }
             ok = ok && hipEventRecord (dc->evStop, stream) == hipSuccess ;
             ok = (hipStreamSynchronize (stream) == hipSuccess) && ok ;

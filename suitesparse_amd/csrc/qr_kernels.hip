@@ -872,6 +872,25 @@ __global__ void __launch_bounds__ (QR_THREADS, 2) k_apply_all (const QrTask *tas
     }
 }
 
+// every update tier and both assemblies in one launch: a round's handful of assembly workgroups ride
+// with the round's updates instead of costing the stream a launch of their own
+__global__ void __launch_bounds__ (QR_THREADS, 2) k_round_all (const QrTask *tasks, const QrRef *refs)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem [] ;
+    const QrRef ref = refs [blockIdx.x] ;
+    const QrTask &t = tasks [ref.task] ;
+    const int type = __builtin_amdgcn_readfirstlane (t.type) ;
+    if (type == QR_TASK_SASSEMBLE) { sassemble (t.u.sasm) ; return ; }
+    if (type == QR_TASK_PACKASSEMBLE) { packassemble (t.u.pack, smem) ; return ; }
+    switch (__builtin_amdgcn_readfirstlane (t.tier))
+    {
+        case 0:  apply_block<2>  (t.u.panel, ref.blk, smem) ; break ;
+        case 1:  apply_block<4>  (t.u.panel, ref.blk, smem) ; break ;
+        case 2:  apply_block<8>  (t.u.panel, ref.blk, smem) ; break ;
+        default: apply_block<16> (t.u.panel, ref.blk, smem) ; break ;
+    }
+}
+
 __global__ void __launch_bounds__ (QR_THREADS) k_assemble (const QrTask *tasks, const QrRef *refs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem [] ;
@@ -892,7 +911,7 @@ static size_t kernel_lds_bytes (int kid)
 {
     if (kid < 4 || kid == 9) return sizeof (FactorizeLds) ;
     if (kid == 10) kid = 6 ;
-    if (kid == 11) kid = 7 ;
+    if (kid == 11 || kid == 12) kid = 7 ;
     if (kid < 8) { size_t rows = (size_t) 32 << (kid - 4) ; return (rows + 32) * VS_LD * 8 + rows * 4 ; }
     return 2 * QR_PACK_TILE * sizeof (int) ;
 }
@@ -1067,6 +1086,7 @@ extern "C" hipError_t qr_launch_tasks_timed (int kid, const QrTask *d_tasks, con
         case 9:  hipExtLaunchKernelGGL (k_factorize_all, grid, fblock, lds, stream, start, stop, 0, d_tasks, d_refs) ; break ;  // tiers 0..3
         case 10: hipExtLaunchKernelGGL (k_apply_small,   grid, block, lds, stream, start, stop, 0, d_tasks, d_refs) ; break ;   // tiers 0..2
         case 11: hipExtLaunchKernelGGL (k_apply_all,     grid, block, lds, stream, start, stop, 0, d_tasks, d_refs) ; break ;   // tiers 0..3
+        case 12: hipExtLaunchKernelGGL (k_round_all,     grid, block, lds, stream, start, stop, 0, d_tasks, d_refs) ; break ;   // tiers 0..3 + assembly
         default: return hipErrorInvalidValue ;
     }
     return hipGetLastError ( ) ;
@@ -1125,6 +1145,9 @@ extern "C" hipError_t qr_kernels_init (void)
         hipFuncAttributeMaxDynamicSharedMemorySize, (int) kernel_lds_bytes (7)) ;
     if (e != hipSuccess) return e ;
     e = hipFuncSetAttribute ((const void *) k_apply_all,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int) kernel_lds_bytes (7)) ;
+    if (e != hipSuccess) return e ;
+    e = hipFuncSetAttribute ((const void *) k_round_all,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int) kernel_lds_bytes (7)) ;
     if (e != hipSuccess) return e ;
     return hipFuncSetAttribute ((const void *) k_persistent,

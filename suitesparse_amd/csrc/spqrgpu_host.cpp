@@ -1420,6 +1420,7 @@ extern "C" int spqrgpu_amd_qtmult
             if (gpuqr_replay_round (qt->rp, r, (void *) 0) != GPUQR_SUCCESS) { code = 2 ; goto done ; }
             const Long p0 = qt->push_ptr [r], p1 = qt->push_ptr [r+1] ;
             if (p1 > p0) HIPCHK (qr_launch_copy_rows ((const QrRowCopy *) qt->dPush.p + p0, p1 - p0, (int) k, 1, 1, 0)) ;
+            if ((r & 511) == 511) HIPCHK (hipStreamSynchronize (0)) ;      // bound on the launches left queued
         }
     }
     HIPCHK (qr_launch_copy_rows ((const QrRowCopy *) qt->dGather.p, qt->ngather, (int) k, 1, qt->rank, 0)) ;

@@ -72,6 +72,10 @@ def main():
                 f.write("%7.2f %s\n" % (__import__("time").time() - t_begin, msg))
 
     trace("start, mode %s" % mode)
+    if os.environ.get("MGPU_SEGV_TRACE"):
+        # debug aid: print the native call stack if this rank dies of a segmentation fault
+        import ctypes
+        ctypes.CDLL(os.environ["MGPU_SEGV_TRACE"])
     if mode == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     elif mode == "gloo-gpu":
