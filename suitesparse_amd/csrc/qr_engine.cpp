@@ -1236,6 +1236,7 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
             pipe_rows = e ? atoi (e) : QR_PANEL_W ;
             if (pipe_rows < QR_PANEL_W || pipe_rows > QR_PACK_TILE || pipe_rows % QR_PANEL_W) pipe_rows = QR_PANEL_W ;
         }
+        plan.tasks.reserve ((size_t) nf * 24) ;        // (a guess that saves most of the regrowth copies)
         struct EvNode { AsmEvent ev ; int64_t next ; } ;
         hvec<EvNode> evpool ;
         hvec<int64_t> ev_head ((size_t) nf, -1) ;

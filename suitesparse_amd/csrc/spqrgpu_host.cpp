@@ -297,6 +297,49 @@ static uint64_t pattern_fingerprint (const int64_t *Ap, const int64_t *Ai, Long 
     return h ;
 }
 
+// Pageable host memory -> device through two page-locked pieces that take turns: the copy of one
+// piece into its page-locked buffer overlaps the DMA of the other.  (A plain hipMemcpy from pageable
+// memory page-locks the caller's buffer first.  The first copy a process makes on the null stream costs
+// about 150 ms either way: the runtime sets its copy queues up then.)
+struct StagedUpload
+{
+    static const size_t piece = (size_t) 8 << 20 ;
+    void *pin [2] = {NULL, NULL} ;
+    hipEvent_t done [2] = {NULL, NULL} ;
+    bool used [2] = {false, false} ;
+    int turn = 0 ;
+    StagedUpload ( )
+    {
+        for (int i = 0 ; i < 2 ; i++)
+        {
+            if (hipHostMalloc (&pin [i], piece, hipHostMallocDefault) != hipSuccess) { pin [i] = NULL ; (void) hipGetLastError ( ) ; }
+            if (hipEventCreateWithFlags (&done [i], hipEventDisableTiming) != hipSuccess) done [i] = NULL ;
+        }
+    }
+    bool ok ( ) const { return pin [0] && pin [1] && done [0] && done [1] ; }
+    hipError_t send (void *dst, const void *src, size_t bytes)
+    {
+        for (size_t off = 0 ; off < bytes ; off += piece)
+        {
+            const size_t len = std::min (piece, bytes - off) ;
+            const int i = turn ; turn ^= 1 ;
+            hipError_t e ;
+            if (used [i] && (e = hipEventSynchronize (done [i])) != hipSuccess) return e ;
+            memcpy (pin [i], (const char *) src + off, len) ;
+            if ((e = hipMemcpyAsync ((char *) dst + off, pin [i], len, hipMemcpyHostToDevice, 0)) != hipSuccess) return e ;
+            if ((e = hipEventRecord (done [i], 0)) != hipSuccess) return e ;
+            used [i] = true ;
+        }
+        return hipSuccess ;
+    }
+    hipError_t finish ( ) { return hipStreamSynchronize (0) ; }
+    ~StagedUpload ( )
+    {
+        (void) hipStreamSynchronize (0) ;
+        for (int i = 0 ; i < 2 ; i++) { if (pin [i]) (void) hipHostFree (pin [i]) ; if (done [i]) (void) hipEventDestroy (done [i]) ; }
+    }
+} ;
+
 static int build_numeric_cache (const spqr_amd_symbolic *S, const int64_t *Ap, const int64_t *Ai)
 {
     spqr_amd_symbolic::NumericCache &C = S->cache ;
@@ -314,6 +357,8 @@ static int build_numeric_cache (const spqr_amd_symbolic *S, const int64_t *Ap, c
     if (C.built) release_numeric_cache (&C) ;
     C.pattern = fp ;
     C.release = release_numeric_cache ;
+    const bool verbose = getenv ("GPUQR_VERBOSE") != NULL ;
+    double tlast = now_ms ( ) ;
     const Long nf = S->nf, n = S->n, m = S->m, anz = S->anz ;
     const Long *Sp = S->Sp.data ( ), *Super = S->Super.data ( ), *Sleft = S->Sleft.data ( ), *Post = S->Post.data ( ) ;
     // position in Ax of every entry of S = A(P,Q) in row form (spqr_stranspose2's scatter)
@@ -333,6 +378,7 @@ static int build_numeric_cache (const spqr_amd_symbolic *S, const int64_t *Ap, c
         }
         for (Long q = 0 ; q < anz ; q++) Sx [q] = (double) q ;      // exact below 2^53
     }
+    TICK ("  cache: A -> S permutation") ;
     const Long RimapSize = std::max ((Long) 1, S->RimapSize), RjmapSize = std::max ((Long) 1, S->RjmapSize) ;
     C.Stair.assign ((size_t) std::max ((Long) 1, S->Rp [nf]), 0) ;
     C.Rimap.assign ((size_t) RimapSize, 0) ; C.Rjmap.assign ((size_t) RjmapSize, 0) ;
@@ -341,6 +387,7 @@ static int build_numeric_cache (const spqr_amd_symbolic *S, const int64_t *Ap, c
     spqrgpu_amd_build_assembly_maps (nf, n, Fmap.data ( ), Post, Super, S->Rp.data ( ), S->Rj.data ( ), Sleft, Sp,
         S->Sj.data ( ), Sx.data ( ), S->Fm.data ( ), S->Cm.data ( ), S->Childp.data ( ), S->Child.data ( ), C.Stair.data ( ),
         C.Rjmap.data ( ), S->RjmapOffsets.data ( ), C.Rimap.data ( ), S->RimapOffsets.data ( ), allS.data ( )) ;
+    TICK ("  cache: assembly maps") ;
     hostvec<Long> findex ((size_t) std::max ((Long) 1, anz)), aperm ((size_t) std::max ((Long) 1, anz)) ;
     for (Long k = 0 ; k < anz ; k++) { findex [k] = allS [k].findex ; aperm [k] = sxperm [(Long) allS [k].value] ; }
     C.SGlob.assign ((size_t) nf + 1, 0) ;
@@ -354,16 +401,25 @@ static int build_numeric_cache (const spqr_amd_symbolic *S, const int64_t *Ap, c
         }
         C.SGlob [nf] = sacc ;
     }
+    TICK ("  cache: findex, aperm") ;
     const size_t nz = (size_t) std::max ((Long) 1, anz) ;
     if (hipMalloc (&C.d_Rimap, (size_t) RimapSize * sizeof (int32_t)) != hipSuccess) { C.d_Rimap = NULL ; release_numeric_cache (&C) ; return 1 ; }
     if (hipMalloc (&C.d_Rjmap, (size_t) RjmapSize * sizeof (int32_t)) != hipSuccess) { C.d_Rjmap = NULL ; release_numeric_cache (&C) ; return 1 ; }
     if (hipMalloc (&C.d_findex, nz * sizeof (Long)) != hipSuccess) { C.d_findex = NULL ; release_numeric_cache (&C) ; return 1 ; }
     if (hipMalloc (&C.d_aperm, nz * sizeof (Long)) != hipSuccess) { C.d_aperm = NULL ; release_numeric_cache (&C) ; return 1 ; }
-    if (hipMemcpy (C.d_Rimap, C.Rimap.data ( ), (size_t) RimapSize * sizeof (int32_t), hipMemcpyHostToDevice) != hipSuccess
-     || hipMemcpy (C.d_Rjmap, C.Rjmap.data ( ), (size_t) RjmapSize * sizeof (int32_t), hipMemcpyHostToDevice) != hipSuccess
-     || hipMemcpy (C.d_findex, findex.data ( ), nz * sizeof (Long), hipMemcpyHostToDevice) != hipSuccess
-     || hipMemcpy (C.d_aperm, aperm.data ( ), nz * sizeof (Long), hipMemcpyHostToDevice) != hipSuccess)
-        { release_numeric_cache (&C) ; return 2 ; }
+    TICK ("  cache: device allocations") ;
+    {
+        StagedUpload up ;
+        TICK ("  cache: staging buffers") ;
+        if (!up.ok ( )
+         || up.send (C.d_Rimap, C.Rimap.data ( ), (size_t) RimapSize * sizeof (int32_t)) != hipSuccess
+         || up.send (C.d_Rjmap, C.Rjmap.data ( ), (size_t) RjmapSize * sizeof (int32_t)) != hipSuccess
+         || up.send (C.d_findex, findex.data ( ), nz * sizeof (Long)) != hipSuccess
+         || up.send (C.d_aperm, aperm.data ( ), nz * sizeof (Long)) != hipSuccess
+         || up.finish ( ) != hipSuccess)
+            { release_numeric_cache (&C) ; return 2 ; }
+    }
+    TICK ("  cache: upload") ;
     C.device = dev ;
     C.built = true ;
     return 0 ;
