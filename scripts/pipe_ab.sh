@@ -1,17 +1,10 @@
-# tests, the child-after-big probe, and A/B runs of the assembly-join threshold
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
 run () { # tag workload env...
   tag=$1; wl=$2; shift 2
   env "$@" timeout -k 10 300 python bench.py --workload $wl --steps 5 --warmup 2 --extras none --no-cpu-baseline > $O/ab_$tag.json 2> $O/ab_$tag.err || exit 1
-  python3 -c "import json;d=json.loads(open('$O/ab_$tag.json').read().strip().splitlines()[-1]);print('$tag',round(d['ms_per_step'],1),round(d['kernel_ms_per_step'],1),d['launches_per_step'])"
+  python3 -c "import json;d=json.loads(open('$O/ab_$tag.json').read().strip().splitlines()[-1]);print('$tag',round(d['ms_per_step'],1),round(d['kernel_ms_per_step'],1),d['launches_per_step'],round(d['cold_first_call_ms'],1))"
 }
-timeout -k 10 200 python -u scripts/dbg/child_after_big.py 64x64x64 2>&1 | grep -v "amdgpu\|^  \|Traceback\|RuntimeError"
 timeout -k 10 600 python -u -m pytest tests/test_sparse_gpu.py tests/test_edges_gpu.py -m gpu -x -q --timeout 120 --timeout-method thread > $O/join_tests.log 2>&1 || { tail -20 $O/join_tests.log; exit 1; }
 tail -2 $O/join_tests.log
-for wl in sparse2d:1024 sparse3d:64; do
-run join0_$wl $wl GPUQR_ASM_JOIN_BELOW=0 &&
-run join256_$wl $wl GPUQR_ASM_JOIN_BELOW=256 &&
-run join1024_$wl $wl GPUQR_ASM_JOIN_BELOW=1024 &&
-run join8192_$wl $wl GPUQR_ASM_JOIN_BELOW=8192 || exit 1
-done
+run final_2d sparse2d:1024 A=1 && run final_3d64 sparse3d:64 A=1 && run final_3d96 sparse3d:96 A=1

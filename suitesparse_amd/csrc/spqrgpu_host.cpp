@@ -425,10 +425,53 @@ static int build_numeric_cache (const spqr_amd_symbolic *S, const int64_t *Ap, c
     return 0 ;
 }
 
+// The page-locked R stack of the last freed numeric object is kept for the next factorization (one
+// per process, until spqrgpu_amd_finalize): page-locking 25 GB for the stack of a 96^3 grid costs
+// 30-100 ms per factorization, 900 ms the first time.
+#include <mutex>
+struct PinnedStackCache
+{
+    std::mutex lock ;
+    void *kept = NULL ; size_t kept_bytes = 0 ;
+    std::vector<std::pair<void *, size_t> > lent ;     // stacks handed out that are larger than their numeric object says
+    void *take (size_t bytes)
+    {
+        std::lock_guard<std::mutex> g (lock) ;
+        if (!kept || kept_bytes < bytes || kept_bytes > 2 * bytes + ((size_t) 64 << 20)) return NULL ;
+        void *p = kept ;
+        try { lent.push_back (std::make_pair (p, kept_bytes)) ; } catch (...) { return NULL ; }
+        kept = NULL ; kept_bytes = 0 ;
+        return p ;
+    }
+    void give (void *p, size_t bytes)
+    {
+        void *drop = NULL ;
+        {
+            std::lock_guard<std::mutex> g (lock) ;
+            for (size_t i = 0 ; i < lent.size ( ) ; i++)
+                if (lent [i].first == p) { bytes = lent [i].second ; lent.erase (lent.begin ( ) + i) ; break ; }
+            drop = kept ;
+            kept = p ; kept_bytes = bytes ;
+        }
+        if (drop) (void) hipHostFree (drop) ;
+    }
+    void clear ( )
+    {
+        void *drop = NULL ;
+        { std::lock_guard<std::mutex> g (lock) ; drop = kept ; kept = NULL ; kept_bytes = 0 ; }
+        if (drop) (void) hipHostFree (drop) ;
+    }
+} ;
+static PinnedStackCache g_pinned_stack ;
+
 extern "C" void spqr_amd_numeric_free (spqr_amd_numeric *num)
 {
     if (!num) return ;
-    if (num->Rstack && !num->RstackBorrowed) { if (num->RstackPinned) (void) hipHostFree (num->Rstack) ; else host_free (num->Rstack) ; }
+    if (num->Rstack && !num->RstackBorrowed)
+    {
+        if (num->RstackPinned) g_pinned_stack.give (num->Rstack, (size_t) std::max ((Long) 1, num->rsize) * sizeof (double)) ;
+        else host_free (num->Rstack) ;
+    }
     host_free (num->Rblock) ; host_free (num->Rdead) ; host_free (num->Cstack) ; host_free (num->Cblock) ;
     host_free (num) ;
 }
@@ -509,6 +552,7 @@ extern "C" void spqrgpu_amd_finalize (void)
         W.dF.release ( ) ; W.dS.release ( ) ; W.dR.release ( ) ; W.dR2.release ( ) ; W.dAx.release ( ) ; W.dTasks.release ( ) ; W.dPrefix.release ( ) ;
         W.hBounce [0].release ( ) ; W.hBounce [1].release ( ) ;
     }
+    g_pinned_stack.clear ( ) ;
     if (cur >= 0) (void) hipSetDevice (cur) ;
 }
 
@@ -675,6 +719,12 @@ static int factorize_impl
                 && hipHostRegister (Rstack_user, (size_t) rtotal * sizeof (double), hipHostRegisterDefault) == hipSuccess)
                 registered = true ;
             else { (void) hipGetLastError ( ) ; num->RstackPinned = 0 ; }
+        }
+        else
+        if (getenv ("GPUQR_PAGEABLE_R") == NULL
+            && (num->Rstack = (double *) g_pinned_stack.take ((size_t) std::max ((Long) 1, rtotal) * sizeof (double))) != NULL)
+        {
+            // the page-locked stack of an earlier factorization
         }
         else
         if (getenv ("GPUQR_PAGEABLE_R") != NULL       // test knob: take the fallback path
