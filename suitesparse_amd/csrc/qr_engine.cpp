@@ -284,12 +284,15 @@ struct AsmEvent { int32_t min_row, round ; } ;
 // round of class c used by the front.  Every task gets round = 1 + the latest round it depends on.
 // ev [0..nev), sorted by min_row: assembly that the front's panels wait for one by one, a panel
 // only for the blocks that reach into the rows it works on.  rows_done (optional) receives, per
-// panel and class, the latest round after which the rows of the panel's diagonal block are final.
+// panel and class, the latest round after which the rows of the panel's diagonal block are final;
+// fact_done (optional), per panel, the round of its last factorize task: columns [0, 32 (p + 1)) of R are
+// final from then on (a column's rows above the panel were finished by earlier panels' updates, which
+// the panel's factorization waited for).
 static void plan_front
 (
     Plan &plan, double *F, int64_t fm, int64_t fn, int64_t ld, const int64_t *Stair,
     int32_t last [QR_NCLASS], bool emit, int64_t rhs_col = 0, int64_t rhs_n = 0,
-    const AsmEvent *ev = NULL, size_t nev = 0, hvec<int32_t> *rows_done = NULL
+    const AsmEvent *ev = NULL, size_t nev = 0, hvec<int32_t> *rows_done = NULL, hvec<int32_t> *fact_done = NULL
 )
 {
     if (fm <= 0 || fn <= 0) return ;
@@ -309,6 +312,7 @@ static void plan_front
     size_t ei = 0 ;             // assembly blocks [0, ei) reach into rows that some panel so far works on
     int32_t asm_run = -1 ;      // latest round among them
     if (rows_done) rows_done->assign ((size_t) npanels * QR_NCLASS, -1) ;
+    if (fact_done) fact_done->assign ((size_t) npanels, -1) ;       // round of each panel's last factorize task
 
     for (int64_t p = 0 ; p < npanels ; p++)
     {
@@ -402,6 +406,7 @@ static void plan_front
         }
         lastw [0][p] = rF0 + nlevels - 1 ;
         last [0] = std::max (last [0], rF0 + nlevels - 1) ;
+        if (fact_done) (*fact_done) [(size_t) p] = rF0 + nlevels - 1 ;
 
         // ---- apply tasks ---------------------------------------------------------
         if (trailing)
@@ -556,10 +561,31 @@ struct LaunchPlan
     hvec<int32_t> bdep ;            // per bucket and class: latest round depended on
     hvec<int32_t> done_last ;       // per front and class: latest round used
     hvec<double> bflops, bbytes ;   // per bucket: flops and algorithmic bytes of its tasks
+    hvec<int64_t> seg_ptr ;         // per front f: [2f] first entry of seg_round, [2f+1] number of entries (0: R goes out whole)
+    hvec<int32_t> seg_round ;       // per piece of QR_RSEG_COLS pivot columns: round from which those columns of R are final
     int32_t nrounds = 0 ;
     int64_t nbuckets = 0, ntasks = 0, nrefs = 0 ;
     int64_t flops = 0 ;
 } ;
+
+// The packed R of a front with at least QR_RSEG_MIN (4096) pivot rows leaves in pieces of QR_RSEG_COLS (512)
+// columns, each as soon as its columns are final, instead of all at once when the front is done: the
+// largest fronts finish last, and their R was what the call still had to send after its last kernel
+// (96^3 grid: 124 -> 92 ms between the last kernel and the end of the step; nothing for a front of
+// 2048 columns, where the extra pack launches cost what the earlier copies save).
+// GPUQR_R_PIECES=0: never; =n > 1: from n pivot rows on, in pieces of n/4 columns (for tests).
+static int g_rseg_cols = 0, g_rseg_min = 0 ;
+static void rseg_setup (void)
+{
+    if (g_rseg_cols != 0) return ;
+    const char *e = getenv ("GPUQR_R_PIECES") ;
+    const int v = e ? atoi (e) : 1 ;
+    if (v == 0) { g_rseg_cols = 512 ; g_rseg_min = INT32_MAX ; }
+    else if (v > 1) { g_rseg_min = std::max (v, 128) ; g_rseg_cols = std::max (32, g_rseg_min / 4 / 32 * 32) ; }
+    else { g_rseg_cols = 512 ; g_rseg_min = 4096 ; }
+}
+#define QR_RSEG_COLS g_rseg_cols
+#define QR_RSEG_MIN  g_rseg_min
 
 // bound on the launches left queued at a time: a checkpoint every QR_CK_EVERY launches, QR_CK_SLOTS of them in flight
 #define QR_CK_EVERY 512
@@ -704,7 +730,7 @@ static double eng_now_ms (void)
 // go on with the rest of the tree.
 struct RPackOut
 {
-    struct Block { int32_t group ; int64_t f ; const char *dev ; char *host ; size_t bytes ; } ;
+    struct Block { int32_t group ; int64_t f ; const char *dev ; char *host ; size_t bytes ; int64_t task ; } ;
     hvec<Block> blocks ;            // sorted by (group, device address)
     hvec<long long> prefix ;        // per group: running count of 32-row tiles, restarting at 0
     hvec<int64_t> gprefix ;         // per block: where its group's counts begin in prefix
@@ -712,19 +738,40 @@ struct RPackOut
     const long long *d_prefix = NULL ;
     size_t pos = 0 ;
 
-    // group_of (f): group of front f; groups are issued in increasing order
-    template <typename G> hipError_t build (DeviceCache *dc, const gpuqr_front *fronts, int64_t nf, G group_of, hipStream_t stream)
+    // group_of (f): group of front f; groups are issued in increasing order.  seg_ptr / seg_round (may be
+    // empty): fronts whose R leaves in pieces of QR_RSEG_COLS columns, with the round from which each piece
+    // is final; group_of_round maps such a round to its group.
+    template <typename G, typename GR> hipError_t build (DeviceCache *dc, const gpuqr_front *fronts, int64_t nf, G group_of,
+        GR group_of_round, const hvec<int64_t> &seg_ptr, const hvec<int32_t> &seg_round, hipStream_t stream)
     {
+        rseg_setup ( ) ;
+        hvec<QrPackRTask> tasks_unsorted ;
+        auto packed_at = [] (int64_t c, int64_t rr) { return (c <= rr) ? c * (c + 1) / 2 : rr * (rr + 1) / 2 + (c - rr) * rr ; } ;
         for (int64_t f = 0 ; f < nf ; f++)
         {
             const gpuqr_front &fr = fronts [f] ;
             if (fr.gpuRpack == NULL || (fr.is_sparse && fr.push_only) || fr.rank <= 0 || fr.fn <= 0 || fr.fm <= 0) continue ;
             const int64_t rr = std::min (fr.rank, fr.fm) ;
-            Block c ;
-            c.group = group_of (f) ; c.f = f ;
-            c.dev = (const char *) fr.gpuRpack ; c.host = (char *) fr.cpuRpack ;
-            c.bytes = (size_t) (rr * (rr + 1) / 2 + rr * (fr.fn - rr)) * sizeof (double) ;
-            blocks.push_back (c) ;
+            const int64_t nseg = ((int64_t) seg_ptr.size ( ) >= 2 * nf) ? seg_ptr [(size_t) 2 * f + 1] : 0 ;
+            for (int64_t k = 0 ; k <= nseg ; k++)
+            {
+                // piece k: columns [k * QR_RSEG_COLS, (k + 1) * QR_RSEG_COLS), the last piece up to fn
+                const int64_t c0 = k * QR_RSEG_COLS, c1 = (k < nseg) ? (k + 1) * QR_RSEG_COLS : fr.fn ;
+                Block c ;
+                c.group = (k < nseg) ? group_of_round (seg_round [(size_t) (seg_ptr [(size_t) 2 * f] + k)]) : group_of (f) ;
+                c.group = std::min (c.group, group_of (f)) ;
+                c.f = f ;
+                const size_t off = (size_t) packed_at (c0, rr) * sizeof (double) ;
+                c.dev = (const char *) fr.gpuRpack + off ;
+                c.host = fr.cpuRpack ? (char *) fr.cpuRpack + off : NULL ;
+                c.bytes = (size_t) (packed_at (c1, rr) - packed_at (c0, rr)) * sizeof (double) ;
+                c.task = (int64_t) tasks_unsorted.size ( ) ;
+                blocks.push_back (c) ;
+                QrPackRTask t ;
+                t.F = fr.gpuF ; t.out = fr.gpuRpack ; t.ld = (int32_t) front_pitch (fr) ; t.fn = (int32_t) fr.fn ;
+                t.frank = (int32_t) rr ; t.c0 = (int32_t) c0 ; t.c1 = (int32_t) c1 ; t.pad = 0 ;
+                tasks_unsorted.push_back (t) ;
+            }
         }
         if (blocks.empty ( )) return hipSuccess ;
         std::sort (blocks.begin ( ), blocks.end ( ), [] (const Block &a, const Block &b)
@@ -733,14 +780,12 @@ struct RPackOut
         gprefix.assign (blocks.size ( ), 0) ;
         for (size_t i = 0 ; i < blocks.size ( ) ; i++)
         {
-            const gpuqr_front &fr = fronts [blocks [i].f] ;
-            const int64_t rr = std::min (fr.rank, fr.fm) ;
-            QrPackRTask &t = tasks [i] ;
-            t.F = fr.gpuF ; t.out = fr.gpuRpack ; t.ld = (int32_t) front_pitch (fr) ; t.fn = (int32_t) fr.fn ;
-            t.frank = (int32_t) rr ; t.pad = 0 ;
+            tasks [i] = tasks_unsorted [(size_t) blocks [i].task] ;
+            // row tiles that hold entries of columns < c1
+            const int64_t rows = std::min<int64_t> (tasks [i].frank, tasks [i].c1) ;
             if (i == 0 || blocks [i].group != blocks [i-1].group) prefix.push_back (0) ;
             gprefix [i] = (i > 0 && blocks [i].group == blocks [i-1].group) ? gprefix [i-1] : (int64_t) prefix.size ( ) - 1 ;
-            prefix.push_back (prefix.back ( ) + (rr + 31) / 32) ;
+            prefix.push_back (prefix.back ( ) + (rows + 31) / 32) ;
         }
         const size_t tbytes = tasks.size ( ) * sizeof (QrPackRTask), pbytes = prefix.size ( ) * sizeof (long long) ;
         hipError_t e = dc->ensure (&dc->d_pack, &dc->cap_pack, tbytes + pbytes, false) ;
@@ -856,7 +901,9 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
             if (rgroup == 0) { const char *e = getenv ("GPUQR_RCOPY_GROUP") ; rgroup = e ? std::max (1, atoi (e)) : 256 ; }
             RPackOut rout ;
             double rout_ms = 0 ; int rout_calls = 0 ;
-            HIP_TRY (rout.build (dc, fronts, nf, [&] (int64_t f) { return std::min (final_round (f), nrounds - 1) / rgroup ; }, sCopy)) ;
+            HIP_TRY (rout.build (dc, fronts, nf, [&] (int64_t f) { return std::min (final_round (f), nrounds - 1) / rgroup ; },
+                [&] (int32_t round) { return std::min (std::max (round, 0), nrounds - 1) / rgroup ; },
+                lp.seg_ptr, lp.seg_round, sCopy)) ;
             // evAt [c][r]: event recorded after the last launch of class c in the latest round <= r that had one
             hvec<hipEvent_t> evAt [QR_NCLASS] ;
             for (int c = 0 ; c < QR_NCLASS ; c++) evAt [c].assign ((size_t) nrounds, (hipEvent_t) NULL) ;
@@ -1157,6 +1204,8 @@ struct Schedule
 {
     Plan plan ;
     hvec<int32_t> done_last ;       // per front and class: latest round used
+    hvec<int64_t> seg_ptr ;         // see LaunchPlan
+    hvec<int32_t> seg_round ;
     hvec<int64_t> rptr ;            // first workgroup of every (round, slot) bucket
     hvec<int32_t> bdep ;            // per bucket and class: latest round depended on
     hvec<double> bflops, bbytes ;   // per bucket: flops and algorithmic bytes of its tasks
@@ -1241,7 +1290,10 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
         hvec<EvNode> evpool ;
         hvec<int64_t> ev_head ((size_t) nf, -1) ;
         hvec<AsmEvent> evs ;
-        hvec<int32_t> rows_done ;
+        hvec<int32_t> rows_done, fact_done ;
+        rseg_setup ( ) ;
+        sc.seg_ptr.assign ((size_t) 2 * nf, 0) ;      // per front: first entry of seg_round, number of entries
+        sc.seg_round.clear ( ) ;
         for (size_t k = 0 ; k < order.size ( ) ; k++)
         {
             const int64_t f = order [k] ;
@@ -1275,7 +1327,14 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
                     if (fr.Scount > 0) last [2] = std::max (last [2], 0) ;
                 }
                 plan_front (plan, fr.gpuF, fr.fm, fr.fn, front_pitch (fr), fr.Stair, last, true, fr.rhs_col, fr.rhs_n,
-                    evs.data ( ), evs.size ( ), &rows_done) ;
+                    evs.data ( ), evs.size ( ), &rows_done, &fact_done) ;
+                // pieces of R: the first rr / QR_RSEG_COLS pieces hold pivot columns only
+                const int64_t rr = std::min (fr.rank, fr.fm) ;
+                sc.seg_ptr [(size_t) 2 * f] = (int64_t) sc.seg_round.size ( ) ;
+                if (fr.gpuRpack != NULL && rr >= QR_RSEG_MIN && !fact_done.empty ( ))
+                    for (int64_t c1 = QR_RSEG_COLS ; c1 <= rr && c1 < fr.fn ; c1 += QR_RSEG_COLS)
+                        sc.seg_round.push_back (fact_done [(size_t) std::min<int64_t> (c1 / QR_PANEL_W - 1, (int64_t) fact_done.size ( ) - 1)]) ;
+                sc.seg_ptr [(size_t) 2 * f + 1] = (int64_t) sc.seg_round.size ( ) - sc.seg_ptr [(size_t) 2 * f] ;
             }
             // blocks that no panel reached into (rows below every panel's) still belong to the front
             for (size_t q = 0 ; q < evs.size ( ) ; q++) last [2] = std::max (last [2], evs [q].round) ;
@@ -1636,7 +1695,9 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
             {
                 // R blocks packed for the caller: one group, behind the kernel
                 RPackOut rout ;
-                HIP_TRY (rout.build (dc, fronts, nf, [] (int64_t) { return 0 ; }, sCopy)) ;
+                static const hvec<int64_t> no_ptr ;
+                static const hvec<int32_t> no_round ;
+                HIP_TRY (rout.build (dc, fronts, nf, [] (int64_t) { return 0 ; }, [] (int32_t) { return 0 ; }, no_ptr, no_round, sCopy)) ;
                 HIP_TRY (rout.issue (0, sCompute)) ;
             }
             for (int64_t f = 0 ; f < nf ; f++)
@@ -1677,6 +1738,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
 
             // the schedule is on the device: remember whose it is, then run it
             lp.rptr.swap (sc.rptr) ; lp.bdep.swap (sc.bdep) ; lp.done_last.swap (sc.done_last) ;
+            lp.seg_ptr.swap (sc.seg_ptr) ; lp.seg_round.swap (sc.seg_round) ;
             lp.nrounds = sc.nrounds ; lp.nbuckets = nbuckets ; lp.ntasks = ntasks ; lp.nrefs = nrefs ; lp.flops = plan.flops ;
             dc->plan_key = plan_key ; dc->plan_nf = nf ;
             lp.bflops.swap (sc.bflops) ; lp.bbytes.swap (sc.bbytes) ;

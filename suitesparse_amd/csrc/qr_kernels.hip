@@ -738,13 +738,14 @@ __global__ void __launch_bounds__ (QR_THREADS) k_pack_r (const QrPackRTask *task
     gdouble *out = (gdouble *) t.out ;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5 ;
     const long long frank = t.frank, tri = frank * (frank + 1) / 2 ;
-    for (int j0 = i0 ; j0 < t.fn ; j0 += 32)
+    // columns [c0, c1) only, from the diagonal on (c0 is a multiple of 32)
+    for (int j0 = (i0 > t.c0) ? i0 : t.c0 ; j0 < t.c1 ; j0 += 32)
     {
         #pragma unroll
         for (int k = 0 ; k < 4 ; k++)
         {
             const int i = i0 + ty + 8*k, j = j0 + tx ;
-            tile [ty + 8*k][tx] = (i < t.frank && j < t.fn) ? F [(size_t) i * t.ld + j] : 0.0 ;
+            tile [ty + 8*k][tx] = (i < t.frank && j < t.c1) ? F [(size_t) i * t.ld + j] : 0.0 ;
         }
         __syncthreads ( ) ;
         #pragma unroll
@@ -752,7 +753,7 @@ __global__ void __launch_bounds__ (QR_THREADS) k_pack_r (const QrPackRTask *task
         {
             const int i = i0 + tx ;
             const long long j = j0 + ty + 8*k ;
-            if (i < t.frank && j < t.fn && j >= i)
+            if (i < t.frank && j < t.c1 && j >= i)
             {
                 const long long col = (j < frank) ? (j * (j + 1) / 2) : (tri + (j - frank) * frank) ;
                 out [col + i] = tile [tx][ty + 8*k] ;

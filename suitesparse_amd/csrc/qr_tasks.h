@@ -93,7 +93,9 @@ struct QrPackRTask
 {
     const double *F;            // reduced front
     double       *out;          // its block of the packed stack
-    int32_t       ld, fn, frank, pad;
+    int32_t       ld, fn, frank;
+    int32_t       c0, c1;       // columns [c0, c1) of R are packed by this task (a front's R may go out in pieces)
+    int32_t       pad;
 };
 
 // One row of a right-hand-side block on its way in, up the tree, or out.

@@ -233,7 +233,7 @@ static double now_ms (void)
 struct QrPackRTask ;
 extern "C" hipError_t qr_launch_pack_r (const QrPackRTask *d_tasks, const long long *d_tile_prefix, int nfronts,
     long long ntiles, hipStream_t stream) ;
-struct PackRTask { const double *F ; double *out ; int32_t ld, fn, frank, pad ; } ;     // = QrPackRTask (qr_tasks.h)
+struct PackRTask { const double *F ; double *out ; int32_t ld, fn, frank, c0, c1, pad ; } ;     // = QrPackRTask (qr_tasks.h)
 extern "C" hipError_t qr_launch_build_s (void *d_S, const long long *d_findex, const long long *d_aperm,
     const double *d_Ax, long long count, hipStream_t stream) ;
 
@@ -1073,7 +1073,7 @@ static int factorize_impl
                     const Long frank = (rp && rp->touched [f]) ? 0 : rank_of (f) ;
                     PackRTask &pt = ptasks [k] ;
                     pt.F = F0 + FOff [k] ; pt.out = (double *) dR.p + ROff [k] ;
-                    pt.ld = (int32_t) pitch [f] ; pt.fn = (int32_t) fn ; pt.frank = (int32_t) frank ; pt.pad = 0 ;
+                    pt.ld = (int32_t) pitch [f] ; pt.fn = (int32_t) fn ; pt.frank = (int32_t) frank ; pt.c0 = 0 ; pt.c1 = (int32_t) fn ; pt.pad = 0 ;
                     prefix [k+1] = prefix [k] + (frank + 31) / 32 ;
                     num->Rblock [f] = rhead + ROff [k] ;
                 }

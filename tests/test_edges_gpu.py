@@ -207,7 +207,8 @@ def test_repeated_device_batches_reuse_the_schedule_and_follow_the_values():
 
 @pytest.mark.parametrize("switch", ["GPUQR_LOOKAHEAD_TILES=2", "GPUQR_LOOKAHEAD_TILES=8", "GPUQR_NO_PIPELINE=1",
                                     "GPUQR_SPLIT_TIERS=1", "GPUQR_RIDE_BELOW=0", "GPUQR_SMALL_ON=0",
-                                    "GPUQR_ASM_JOIN_BELOW=0", "GPUQR_EVENT_RING=16", "GPUQR_PIPE_ROWS=128"])
+                                    "GPUQR_ASM_JOIN_BELOW=0", "GPUQR_EVENT_RING=16", "GPUQR_PIPE_ROWS=128",
+                                    "GPUQR_R_PIECES=128", "GPUQR_R_PIECES=0", "GPUQR_RCOPY_GROUP=8"])
 def test_schedule_switches_in_a_fresh_process(tmp_path, switch):
     """The schedule switches change which tasks share a launch and which stream runs them, never the
     arithmetic of a task: a process started with one of them set must produce bit-identical R for a
