@@ -122,6 +122,29 @@ extern "C" int64_t spqrgpu_amd_numfronts_in_stage
 // assembly maps
 // -----------------------------------------------------------------------------
 
+#include <thread>
+#include <atomic>
+
+// Run body(k) for k in [0,n) on a few host threads (dynamic, one index at a time).
+template <class Body> static void parallel_for (Long n, Body body, Long serial_below = 64)
+{
+    unsigned hw = std::thread::hardware_concurrency ( ) ;
+    const char *env = getenv ("OMP_NUM_THREADS") ;
+    long want = env ? atol (env) : 16 ;
+    if (want < 1) want = 1 ;
+    unsigned nt = (unsigned) std::min<long> (want, hw ? hw : 1) ;
+    if (nt > 16) nt = 16 ;
+    if (n < serial_below || n < 2 || nt <= 1) { for (Long k = 0 ; k < n ; k++) body (k) ; return ; }
+    std::atomic<Long> next (0) ;
+    std::vector<std::thread> pool ;
+    const Long grain = (n >= 1024) ? 16 : 1 ;
+    auto work = [&] ( ) { for (Long k = next.fetch_add (grain) ; k < n ; k = next.fetch_add (grain))
+        for (Long q = k ; q < std::min (k + grain, n) ; q++) body (q) ; } ;
+    for (unsigned t = 1 ; t < nt ; t++) pool.emplace_back (work) ;
+    work ( ) ;
+    for (size_t t = 0 ; t < pool.size ( ) ; t++) pool [t].join ( ) ;
+}
+
 // Per front, in postorder: the staircase, the column map of every child's
 // contribution block (Rjmap), the packed S entries with their position in the
 // front, and the row each child row lands in (Rimap).  Rows of a front are laid
@@ -138,11 +161,21 @@ extern "C" void spqrgpu_amd_build_assembly_maps
     int32_t *CompleteRimap, const int64_t *RimapOffsets, gpuqr_sentry *cpuS
 )
 {
-    (void) n ; (void) Fm ;
-    Long snext = 0 ;
+    (void) Fm ;
+    // where the S entries of the k-th front (in Post order) start: they are written front after front
+    std::vector<Long> soff ((size_t) numFronts + 1, 0) ;
     for (Long k = 0 ; k < numFronts ; k++)
     {
         const Long f = Post [k] ;
+        soff [(size_t) k + 1] = soff [(size_t) k] + (Sp [Sleft [Super [f+1]]] - Sp [Sleft [Super [f]]]) ;
+    }
+    // One front at a time, and no front touches what another one writes (its own staircase, its
+    // children's maps, its own stretch of cpuS): many fronts are done by several threads, each with
+    // a column map of its own (the caller's Fmap serves the first).
+    auto one_front = [&] (Long k, Long *Fmap)
+    {
+        const Long f = Post [k] ;
+        Long snext = soff [(size_t) k] ;
         const Long col1 = Super [f], fp = Super [f+1] - col1, fn = Rp [f+1] - Rp [f] ;
         Long *Stair = CompleteStair + Rp [f] ;
         for (Long j = 0 ; j < fn ; j++) Fmap [Rj [Rp [f] + j]] = j ;
@@ -185,35 +218,41 @@ extern "C" void spqrgpu_amd_build_assembly_maps
             const int32_t *Rjmap = CompleteRjmap + RjmapOffsets [c] ;
             for (Long i = 0 ; i < Cm [c] ; i++) Rimap [i] = (int32_t) (Stair [Rjmap [i]]++) ;
         }
+    } ;
+    unsigned nt = 1 ;
+    if (numFronts >= 4096)
+    {
+        const unsigned hw = std::thread::hardware_concurrency ( ) ;
+        const char *env = getenv ("OMP_NUM_THREADS") ;
+        const long want = env ? atol (env) : 16 ;
+        nt = (unsigned) std::max<long> (1, std::min<long> (std::min<long> (want, hw ? hw : 1), 8)) ;
     }
+    std::vector<Long *> maps (nt, (Long *) NULL) ;
+    maps [0] = Fmap ;
+    for (unsigned t = 1 ; t < nt ; t++)
+    {
+        maps [t] = (Long *) malloc ((size_t) std::max ((Long) 1, n) * sizeof (Long)) ;
+        if (!maps [t]) { nt = t ; break ; }         // fewer threads, then
+    }
+    std::atomic<Long> next (0) ;
+    const Long grain = 64 ;
+    auto work = [&] (unsigned t)
+    {
+        for (Long k0 = next.fetch_add (grain) ; k0 < numFronts ; k0 = next.fetch_add (grain))
+            for (Long k = k0 ; k < std::min (k0 + grain, numFronts) ; k++) one_front (k, maps [t]) ;
+    } ;
+    {
+        std::vector<std::thread> pool ;
+        try { for (unsigned t = 1 ; t < nt ; t++) pool.emplace_back (work, t) ; } catch (...) { }
+        work (0) ;
+        for (size_t t = 0 ; t < pool.size ( ) ; t++) pool [t].join ( ) ;
+    }
+    for (unsigned t = 1 ; t < maps.size ( ) ; t++) free (maps [t]) ;
 }
 
 // -----------------------------------------------------------------------------
 // numeric driver
 // -----------------------------------------------------------------------------
-
-#include <thread>
-#include <atomic>
-
-// Run body(k) for k in [0,n) on a few host threads (dynamic, one index at a time).
-template <class Body> static void parallel_for (Long n, Body body, Long serial_below = 64)
-{
-    unsigned hw = std::thread::hardware_concurrency ( ) ;
-    const char *env = getenv ("OMP_NUM_THREADS") ;
-    long want = env ? atol (env) : 16 ;
-    if (want < 1) want = 1 ;
-    unsigned nt = (unsigned) std::min<long> (want, hw ? hw : 1) ;
-    if (nt > 16) nt = 16 ;
-    if (n < serial_below || n < 2 || nt <= 1) { for (Long k = 0 ; k < n ; k++) body (k) ; return ; }
-    std::atomic<Long> next (0) ;
-    std::vector<std::thread> pool ;
-    const Long grain = (n >= 1024) ? 16 : 1 ;
-    auto work = [&] ( ) { for (Long k = next.fetch_add (grain) ; k < n ; k = next.fetch_add (grain))
-        for (Long q = k ; q < std::min (k + grain, n) ; q++) body (q) ; } ;
-    for (unsigned t = 1 ; t < nt ; t++) pool.emplace_back (work) ;
-    work ( ) ;
-    for (size_t t = 0 ; t < pool.size ( ) ; t++) pool [t].join ( ) ;
-}
 
 static inline Long r_block_size (Long fn, Long frank)
 {
@@ -389,7 +428,14 @@ static int build_numeric_cache (const spqr_amd_symbolic *S, const int64_t *Ap, c
         C.Rjmap.data ( ), S->RjmapOffsets.data ( ), C.Rimap.data ( ), S->RimapOffsets.data ( ), allS.data ( )) ;
     TICK ("  cache: assembly maps") ;
     hostvec<Long> findex ((size_t) std::max ((Long) 1, anz)), aperm ((size_t) std::max ((Long) 1, anz)) ;
-    for (Long k = 0 ; k < anz ; k++) { findex [k] = allS [k].findex ; aperm [k] = sxperm [(Long) allS [k].value] ; }
+    {
+        const Long chunk = (Long) 1 << 18 ;
+        parallel_for ((anz + chunk - 1) / chunk, [&] (Long c)
+        {
+            for (Long k = c * chunk ; k < std::min (anz, (c + 1) * chunk) ; k++)
+                { findex [k] = allS [k].findex ; aperm [k] = sxperm [(Long) allS [k].value] ; }
+        }, 2) ;
+    }
     C.SGlob.assign ((size_t) nf + 1, 0) ;
     {
         Long sacc = 0 ;

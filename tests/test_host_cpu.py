@@ -118,6 +118,21 @@ def test_assembly_maps_bit_exact(name, A, Q):
         assert np.all(np.diff(st) >= 0) and st[-1] == sym.Fm[f]
 
 
+def test_assembly_maps_of_many_fronts_on_several_threads_bit_exact():
+    """From 4096 fronts on the maps are built by several host threads, front by front: same arrays, bit
+    for bit, as the oracle's single loop (and as a second run: no order dependence)."""
+    shape = (300, 300)
+    A = problems.stacked_ls(shape)
+    sym = spqr.analyze(A, problems.nested_dissection(shape, leaf=3), relax=0, gpuMemorySize=2**36)
+    assert sym.nf >= 4096
+    Sx = spqr.s_values(sym, A)
+    got = spqr.spqrgpu_buildAssemblyMaps(sym, Sx)
+    ref = oracle.build_assembly_maps(sym, Sx)
+    again = spqr.spqrgpu_buildAssemblyMaps(sym, Sx)
+    for g, r, a in zip(got, ref, again):
+        assert g.tobytes() == r.tobytes() and a.tobytes() == r.tobytes()
+
+
 @pytest.mark.parametrize("name,A,Q", list(_cases()), ids=[c[0] for c in _cases()])
 @pytest.mark.parametrize("mem", [0, 1, 2**21, 2**22 + 12345, 11_000_000, 2**33])
 def test_staging_bit_exact(name, A, Q, mem):
