@@ -86,7 +86,7 @@ void spqrgpu_kernel (spqr_blob <Complex> *Blob)
 
 // void spqrgpu_computeFrontStaging (...) (SPQR/Include/spqrgpu.hpp:16-57) and
 // void spqrgpu_buildAssemblyMaps (...) (spqrgpu.hpp:59-82) bind to
-// spqrgpu_amd_compute_front_staging / spqrgpu_amd_build_assembly_maps the same way; the two wrappers
-// are shown in INTEGRATION.md.
+// spqrgpu_amd_compute_front_staging / spqrgpu_amd_build_assembly_maps the same way: same arguments in
+// the same order, cc->gpuMemorySize passed by value.
 
 #endif

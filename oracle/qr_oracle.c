@@ -13,7 +13,8 @@
  * qrtest bars ||R'R-(AP)'(AP)||_1/||A'A||_1 <= 1e-10, residual <= 1e-10
  * (SPQR/Tcov/qrtest.cpp:1218-1257,2750-2763); (2) uniqueness of R up to row
  * signs, checked against LAPACK (numpy) in tests/test_oracle.py; (3) the
- * staging outcomes the survey recorded from the reference's own function.
+ * staging outcomes of the reference's own function at gpuMemorySize 1e10, 0 and 1 (one stage; an
+ * empty stage plus one front per stage; infeasible).
  * Integer outputs (staging, assembly maps, S scatter, pack assembly) are
  * compared bit for bit with the product.
  */

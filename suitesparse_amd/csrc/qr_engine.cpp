@@ -14,7 +14,7 @@
 // independently (level 0); the 32-row R factors on top of the chunks are then
 // merged 8 at a time (levels 1, 2, ...) until one R remains in the diagonal
 // block - a communication-avoiding (TSQR) panel, the generalisation of the
-// reference's bundles of three 32-row tiles (SURVEY of the tile schedule:
+// reference's bundles of three 32-row tiles (its tile schedule:
 // GPUQREngine/Source/BucketList/BucketList_CreateBundles.cpp:15-54,
 // LLBundle_Advance.cpp:19-80).  Every factorize task leaves a VT tile, and
 // apply tasks push its block reflector through the trailing columns, level by

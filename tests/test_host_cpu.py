@@ -287,8 +287,8 @@ def test_qrdemo_west0067_rank_and_residual():
     """BASELINE config 1 on the one bundled matrix the reference tree still holds, read in place
     (never copied): analysis, the oracle's multifrontal QR, least squares through an appended b = ones
     as SPQR/Demo/qrdemo.cpp:87-105 sets it up, and qrdemo's own check (qrdemo.cpp:22-70):
-    rank 67 and ||Ax-b||_2 / (||A||_1 ||x||_2) at rounding level (the reference built in the survey's
-    scratch directory printed 6.8e-17 for its default ordering)."""
+    rank 67 and ||Ax-b||_2 / (||A||_1 ||x||_2) at rounding level (a build of the reference printed
+    6.8e-17 for its default ordering)."""
     import scipy.io
     A = sp.csc_matrix(scipy.io.hb_read(WEST0067))
     m, n = A.shape
