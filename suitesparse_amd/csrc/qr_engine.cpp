@@ -27,6 +27,8 @@
 #include <string.h>
 #include <stdio.h>
 #include <vector>
+#include <thread>
+#include <atomic>
 #include <algorithm>
 #include <new>
 
@@ -1213,6 +1215,25 @@ struct Schedule
     int64_t nbuckets = 0, ntasks = 0, nrefs = 0 ;
 } ;
 
+// body (c) for c in [0, n), on a few host threads when there are many chunks (c is handed out one at a time)
+template <class Body> static void run_chunks (int64_t n, Body body)
+{
+    unsigned nt = 1 ;
+    if (n >= 8 && !g_host_arena_on)         // (the entry point that allocates nothing starts no threads either)
+    {
+        const unsigned hw = std::thread::hardware_concurrency ( ) ;
+        const char *env = getenv ("OMP_NUM_THREADS") ;
+        const long want = env ? atol (env) : 16 ;
+        nt = (unsigned) std::max<long> (1, std::min<long> (std::min<long> (want, hw ? hw : 1), 8)) ;
+    }
+    std::atomic<int64_t> next (0) ;
+    auto work = [&] ( ) { for (int64_t c = next.fetch_add (1) ; c < n ; c = next.fetch_add (1)) body (c) ; } ;
+    std::vector<std::thread> pool ;
+    try { for (unsigned t = 1 ; t < nt ; t++) pool.emplace_back (work) ; } catch (...) { }
+    work ( ) ;
+    for (size_t t = 0 ; t < pool.size ( ) ; t++) pool [t].join ( ) ;
+}
+
 // Validate the fronts, order them children first, emit their tasks and sort the workgroups by
 // (round, launch slot).  Host work only.
 static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const bool eng_verbose, double &eng_tlast)
@@ -1285,7 +1306,22 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
             pipe_rows = e ? atoi (e) : QR_PANEL_W ;
             if (pipe_rows < QR_PANEL_W || pipe_rows > QR_PACK_TILE || pipe_rows % QR_PANEL_W) pipe_rows = QR_PANEL_W ;
         }
-        plan.tasks.reserve ((size_t) nf * 24) ;        // (a guess that saves most of the regrowth copies)
+        {
+            // an upper bound on the tasks, so that the vector never regrows (regrowth copied 1.6 GB for a
+            // 96^3 grid): per panel one factorize and one update task per 256-row chunk and merge
+            double est = 0 ;
+            for (int64_t f = 0 ; f < nf ; f++)
+            {
+                const gpuqr_front &fr = fronts [f] ;
+                if (fr.fm <= 0 || fr.fn <= 0) continue ;
+                const double npan = (double) ((std::min (fr.fm, fr.fn) + QR_PANEL_W - 1) / QR_PANEL_W) ;
+                const double nch = (double) ((fr.fm + QR_MAX_K - 1) / QR_MAX_K) ;
+                est += npan * (2.3 * nch + 6) * (fr.rhs_n > 0 ? 1.5 : 1.0)
+                    + (double) (fr.Scount / QR_SASM_CHUNK + 1)
+                    + (double) (fr.cm / QR_PANEL_W + 1) * (double) (fr.cn / QR_PACK_TILE + 1) ;
+            }
+            if (est < 4e9 / sizeof (SchedTask)) plan.tasks.reserve ((size_t) est) ;
+        }
         struct EvNode { AsmEvent ev ; int64_t next ; } ;
         hvec<EvNode> evpool ;
         hvec<int64_t> ev_head ((size_t) nf, -1) ;
@@ -1505,28 +1541,41 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
 // by, and write the task records and the (task, block) list of the workgroups in launch order.
 static int stage_tasks (Schedule &sc, double *d_vt, QrTask *h_tasks, QrRef *h_refs)
 {
-    hvec<int64_t> pos (sc.rptr) ;
+    // where each task's workgroups go in the launch-ordered list: tasks of a bucket in task order
+    hvec<int64_t> pos (sc.rptr), at ((size_t) sc.ntasks) ;
     for (int64_t i = 0 ; i < sc.ntasks ; i++)
     {
-        SchedTask &st = sc.plan.tasks [i] ;
-        if (st.t.type == QR_TASK_FACTORIZE || st.t.type == QR_TASK_APPLY)
-        {
-            QrPanelTask &pt = st.t.u.panel ;
-            pt.VT = (st.vt >= 0) ? d_vt + (size_t) st.vt * QR_VT_DOUBLES : NULL ;
-            bool ok = pt.K >= 1 && pt.K <= QR_MAX_K && pt.w >= 1 && pt.w <= QR_PANEL_W
-                && pt.nseg >= 1 && pt.nseg <= QR_MAX_SEG && pt.col0 >= 0 && pt.col0 + pt.w <= pt.ld
-                && (st.t.type == QR_TASK_FACTORIZE || (pt.VT != NULL && pt.c_begin >= 0
-                    && pt.c_begin < pt.c_end && pt.c_end <= pt.ld && pt.cb_cols >= 16
-                    && (int64_t) (st.nblk - 1) * pt.cb_cols < pt.c_end - pt.c_begin)) ;
-            int acc = 0 ;
-            for (int s = 0 ; s < pt.nseg && ok ; s++) { ok = pt.seg_row [s] >= 0 && pt.seg_n [s] >= 1 ; acc += pt.seg_n [s] ; }
-            if (!ok || acc != pt.K) return GPUQR_GPUERROR ;
-        }
-        h_tasks [i] = st.t ;
+        const SchedTask &st = sc.plan.tasks [i] ;
         int64_t &q = pos [(int64_t) st.round * QR_NSLOTS + st.slot] ;
-        for (int32_t b = 0 ; b < st.nblk ; b++) { h_refs [q].task = (int32_t) i ; h_refs [q].blk = b ; q++ ; }
+        at [(size_t) i] = q ;
+        q += st.nblk ;
     }
-    return GPUQR_SUCCESS ;
+    std::atomic<int> bad (0) ;
+    const int64_t chunk = 8192 ;
+    run_chunks ((sc.ntasks + chunk - 1) / chunk, [&] (int64_t c)
+    {
+        for (int64_t i = c * chunk ; i < std::min (sc.ntasks, (c + 1) * chunk) ; i++)
+        {
+            SchedTask &st = sc.plan.tasks [i] ;
+            if (st.t.type == QR_TASK_FACTORIZE || st.t.type == QR_TASK_APPLY)
+            {
+                QrPanelTask &pt = st.t.u.panel ;
+                pt.VT = (st.vt >= 0) ? d_vt + (size_t) st.vt * QR_VT_DOUBLES : NULL ;
+                bool ok = pt.K >= 1 && pt.K <= QR_MAX_K && pt.w >= 1 && pt.w <= QR_PANEL_W
+                    && pt.nseg >= 1 && pt.nseg <= QR_MAX_SEG && pt.col0 >= 0 && pt.col0 + pt.w <= pt.ld
+                    && (st.t.type == QR_TASK_FACTORIZE || (pt.VT != NULL && pt.c_begin >= 0
+                        && pt.c_begin < pt.c_end && pt.c_end <= pt.ld && pt.cb_cols >= 16
+                        && (int64_t) (st.nblk - 1) * pt.cb_cols < pt.c_end - pt.c_begin)) ;
+                int acc = 0 ;
+                for (int s = 0 ; s < pt.nseg && ok ; s++) { ok = pt.seg_row [s] >= 0 && pt.seg_n [s] >= 1 ; acc += pt.seg_n [s] ; }
+                if (!ok || acc != pt.K) bad.store (1) ;
+            }
+            h_tasks [i] = st.t ;
+            int64_t q = at [(size_t) i] ;
+            for (int32_t b = 0 ; b < st.nblk ; b++) { h_refs [q].task = (int32_t) i ; h_refs [q].blk = b ; q++ ; }
+        }
+    }) ;
+    return bad.load ( ) ? GPUQR_GPUERROR : GPUQR_SUCCESS ;
 }
 
 static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint64_t plan_key)
