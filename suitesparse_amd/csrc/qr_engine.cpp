@@ -573,7 +573,7 @@ struct LaunchPlan
 // The packed R of a front with at least QR_RSEG_MIN (4096) pivot rows leaves in pieces of QR_RSEG_COLS (512)
 // columns, each as soon as its columns are final, instead of all at once when the front is done: the
 // largest fronts finish last, and their R was what the call still had to send after its last kernel
-// (96^3 grid: 124 -> 92 ms between the last kernel and the end of the step; nothing for a front of
+// (96^3 grid: 124 -> 42 ms between the last kernel and the end of the step; nothing for a front of
 // 2048 columns, where the extra pack launches cost what the earlier copies save).
 // GPUQR_R_PIECES=0: never; =n > 1: from n pivot rows on, in pieces of n/4 columns (for tests).
 static int g_rseg_cols = 0, g_rseg_min = 0 ;
@@ -754,13 +754,15 @@ struct RPackOut
             const gpuqr_front &fr = fronts [f] ;
             if (fr.gpuRpack == NULL || (fr.is_sparse && fr.push_only) || fr.rank <= 0 || fr.fn <= 0 || fr.fm <= 0) continue ;
             const int64_t rr = std::min (fr.rank, fr.fm) ;
-            const int64_t nseg = ((int64_t) seg_ptr.size ( ) >= 2 * nf) ? seg_ptr [(size_t) 2 * f + 1] : 0 ;
+            // (a front that goes out in pieces has one round per piece, the last piece included)
+            const int64_t nent = ((int64_t) seg_ptr.size ( ) >= 2 * nf) ? seg_ptr [(size_t) 2 * f + 1] : 0 ;
+            const int64_t nseg = (nent > 0) ? nent - 1 : 0 ;
             for (int64_t k = 0 ; k <= nseg ; k++)
             {
                 // piece k: columns [k * QR_RSEG_COLS, (k + 1) * QR_RSEG_COLS), the last piece up to fn
                 const int64_t c0 = k * QR_RSEG_COLS, c1 = (k < nseg) ? (k + 1) * QR_RSEG_COLS : fr.fn ;
                 Block c ;
-                c.group = (k < nseg) ? group_of_round (seg_round [(size_t) (seg_ptr [(size_t) 2 * f] + k)]) : group_of (f) ;
+                c.group = (k < nent) ? group_of_round (seg_round [(size_t) (seg_ptr [(size_t) 2 * f] + k)]) : group_of (f) ;
                 c.group = std::min (c.group, group_of (f)) ;
                 c.f = f ;
                 const size_t off = (size_t) packed_at (c0, rr) * sizeof (double) ;
@@ -1367,9 +1369,18 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
                 // pieces of R: the first rr / QR_RSEG_COLS pieces hold pivot columns only
                 const int64_t rr = std::min (fr.rank, fr.fm) ;
                 sc.seg_ptr [(size_t) 2 * f] = (int64_t) sc.seg_round.size ( ) ;
-                if (fr.gpuRpack != NULL && rr >= QR_RSEG_MIN && !fact_done.empty ( ))
+                if (fr.gpuRpack != NULL && rr >= QR_RSEG_MIN && !fact_done.empty ( ) && !rows_done.empty ( ))
+                {
                     for (int64_t c1 = QR_RSEG_COLS ; c1 <= rr && c1 < fr.fn ; c1 += QR_RSEG_COLS)
                         sc.seg_round.push_back (fact_done [(size_t) std::min<int64_t> (c1 / QR_PANEL_W - 1, (int64_t) fact_done.size ( ) - 1)]) ;
+                    // the last piece (the rest of the pivot columns and every other column): its rows are
+                    // final once the panel of the last row of R has been applied to all columns, long
+                    // before the front is through with its contribution block
+                    const size_t pl = (size_t) std::min<int64_t> ((rr - 1) / QR_PANEL_W, (int64_t) fact_done.size ( ) - 1) ;
+                    int32_t rlast = -1 ;
+                    for (int c = 0 ; c < QR_NCLASS ; c++) rlast = std::max (rlast, rows_done [pl * QR_NCLASS + c]) ;
+                    sc.seg_round.push_back (rlast) ;
+                }
                 sc.seg_ptr [(size_t) 2 * f + 1] = (int64_t) sc.seg_round.size ( ) - sc.seg_ptr [(size_t) 2 * f] ;
             }
             // blocks that no panel reached into (rows below every panel's) still belong to the front
