@@ -1369,13 +1369,14 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
                 // pieces of R: the first rr / QR_RSEG_COLS pieces hold pivot columns only
                 const int64_t rr = std::min (fr.rank, fr.fm) ;
                 sc.seg_ptr [(size_t) 2 * f] = (int64_t) sc.seg_round.size ( ) ;
-                if (fr.gpuRpack != NULL && rr >= QR_RSEG_MIN && !fact_done.empty ( ) && !rows_done.empty ( ))
+                if (fr.gpuRpack != NULL && rr > 0 && !fact_done.empty ( ) && !rows_done.empty ( ))
                 {
-                    for (int64_t c1 = QR_RSEG_COLS ; c1 <= rr && c1 < fr.fn ; c1 += QR_RSEG_COLS)
-                        sc.seg_round.push_back (fact_done [(size_t) std::min<int64_t> (c1 / QR_PANEL_W - 1, (int64_t) fact_done.size ( ) - 1)]) ;
-                    // the last piece (the rest of the pivot columns and every other column): its rows are
-                    // final once the panel of the last row of R has been applied to all columns, long
-                    // before the front is through with its contribution block
+                    if (rr >= QR_RSEG_MIN)
+                        for (int64_t c1 = QR_RSEG_COLS ; c1 <= rr && c1 < fr.fn ; c1 += QR_RSEG_COLS)
+                            sc.seg_round.push_back (fact_done [(size_t) std::min<int64_t> (c1 / QR_PANEL_W - 1, (int64_t) fact_done.size ( ) - 1)]) ;
+                    // the last piece (the rest of the pivot columns and every other column; the whole R of a
+                    // smaller front): its rows are final once the panel of the last row of R has been applied
+                    // to all columns, long before the front is through with its contribution block
                     const size_t pl = (size_t) std::min<int64_t> ((rr - 1) / QR_PANEL_W, (int64_t) fact_done.size ( ) - 1) ;
                     int32_t rlast = -1 ;
                     for (int c = 0 ; c < QR_NCLASS ; c++) rlast = std::max (rlast, rows_done [pl * QR_NCLASS + c]) ;
