@@ -179,6 +179,41 @@ def test_tree_mapped_ranks_on_one_gpu(tmp_path, world, shape):
     assert r_rel_diff(rownorm_sign(R), rownorm_sign(Rl)) <= 1e-12
 
 
+def test_four_ranks_give_the_single_process_r_bit_for_bit(tmp_path):
+    """Four processes on the one GPU, a 3D grid with three levels of the rank map: the ranks run the
+    same tasks on the same numbers as one process does, contribution blocks are copied, never summed,
+    so R must agree bit for bit with the single-process factorization."""
+    import os
+    import signal
+    import subprocess
+    import sys
+    from suitesparse_amd import _lib
+    _lib.lib().spqrgpu_amd_finalize()
+    _lib.lib().gpuqr_finalize()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out, shape = str(tmp_path / "R.npz"), "24x24x24"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + (os.getpid() % 2000) + 9000),
+           os.path.join(root, "tests", "mgpu_worker.py"), "gloo-gpu", out, shape]
+    with open(str(tmp_path / "out.txt"), "w") as fo:
+        proc = subprocess.Popen(cmd, stdout=fo, stderr=subprocess.STDOUT, start_new_session=True)
+        try:
+            proc.wait(timeout=150)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.wait(timeout=20)
+            raise AssertionError("multi-rank run hung:\n" + open(str(tmp_path / "out.txt")).read()[-3000:])
+    assert proc.returncode == 0, open(str(tmp_path / "out.txt")).read()[-6000:]
+    z = np.load(out)
+    R = sp.csc_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"]))
+    dims = (24, 24, 24)
+    A = problems.stacked_ls(dims)
+    sym = spqr.analyze(A, problems.nested_dissection(dims, leaf=3), relax=0, gpuMemorySize=2**34)
+    one = spqr.factorize(sym, A).R.tocsc()
+    assert int(z["levels"]) >= 3 and int(z["n_cut"]) >= 3
+    assert R.shape == one.shape and R.nnz == one.nnz and (R != one).nnz == 0
+
+
 @pytest.mark.parametrize("mem", [0, 14_000_000, 2**34])
 @pytest.mark.parametrize("dev_blocks", [False, True])
 def test_subset_driver_in_groups_and_pieces(mem, dev_blocks):
