@@ -2,12 +2,12 @@
 // 256-row tasks, every task split into column blocks.  Build variants with -D flags.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -I suitesparse_amd/csrc scripts/ubench/apply_bench.hip -o scripts/ubench/apply_bench
 // -DNOMFMA: timing-only build, the matrix instructions are replaced by one add that keeps the operands
-// alive; -DNT: the trailing matrix is loaded and stored with the non-temporal hint.
+// alive; -DNT_SLABS: the trailing matrix is loaded and stored with the non-temporal hint.
 #ifdef NOMFMA
 typedef double v4f64_ub __attribute__((ext_vector_type(4)));
 #define MFMA64(a, b, c) ((c) + (v4f64_ub) {(a) * (b), 0.0, 0.0, 0.0})
 #endif
-#ifdef NT
+#ifdef NT_SLABS
 #define SLAB_LOAD(p) __builtin_nontemporal_load (p)
 #define SLAB_STORE(v, p) __builtin_nontemporal_store ((v), (p))
 #endif

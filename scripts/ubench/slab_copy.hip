@@ -45,6 +45,25 @@ __global__ void __launch_bounds__(256, 2) k (double *Fp, int ld, int nslab_per_w
             #pragma unroll
             for (int i = 0 ; i < 64 ; i++) F [(row0 + 4*i + r4) * ld + col0 + c] = a [i] + 1.0 ;
         }
+        else if (MODE == 16 || MODE == 17 || MODE == 18)
+        {
+            // x4 with non-temporal loads (16, 18) and stores (17, 18)
+            d2 a [32] ;
+            const int r8 = lane >> 3, j = lane & 7 ;
+            #pragma unroll
+            for (int i = 0 ; i < 32 ; i++)
+            {
+                gd2 *q = (gd2 *) (F + (row0 + 8*i + r8) * ld + col0 + 2*j) ;
+                a [i] = (MODE != 17) ? __builtin_nontemporal_load (q) : *q ;
+            }
+            #pragma unroll
+            for (int i = 0 ; i < 32 ; i++)
+            {
+                d2 v = a [i] ; v.x += 1.0 ; v.y += 1.0 ;
+                gd2 *q = (gd2 *) (F + (row0 + 8*i + r8) * ld + col0 + 2*j) ;
+                if (MODE != 16) __builtin_nontemporal_store (v, q) ; else *q = v ;
+            }
+        }
         else
         {
             d2 a [32] ;
@@ -108,6 +127,23 @@ int main (int argc, char **argv)
             if (r > 0 && ms < best) best = ms ;
         }
         printf ("row: tasks %d cols %d cb %d  %.3f ms  %.2f TB/s\n", ntask, ncols, cb, best, (double) rows * ncols * 16 / best / 1e9) ;
+    }
+    for (int mode = 16 ; mode <= 18 ; mode++)
+    {
+        float best = 1e30f ;
+        int bpt = ncols / cb ;
+        for (int r = 0 ; r < 6 ; r++)
+        {
+            hipEventRecord (e0) ;
+            if (mode == 16)      hipLaunchKernelGGL (k<16>, dim3 (ntask * bpt), dim3 (256), 0, 0, F, ld, cb / 16, bpt) ;
+            else if (mode == 17) hipLaunchKernelGGL (k<17>, dim3 (ntask * bpt), dim3 (256), 0, 0, F, ld, cb / 16, bpt) ;
+            else                 hipLaunchKernelGGL (k<18>, dim3 (ntask * bpt), dim3 (256), 0, 0, F, ld, cb / 16, bpt) ;
+            hipEventRecord (e1) ; hipEventSynchronize (e1) ;
+            float ms ; hipEventElapsedTime (&ms, e0, e1) ;
+            if (r > 0 && ms < best) best = ms ;
+        }
+        printf ("x4 non-temporal %s: tasks %d cols %d cb %d  %.3f ms  %.2f TB/s\n", mode == 16 ? "loads" : (mode == 17 ? "stores" : "loads and stores"),
+            ntask, ncols, cb, best, (double) rows * ncols * 16 / best / 1e9) ;
     }
     for (int wgs = 2048 ; wgs <= 32768 ; wgs *= 4)
     {
