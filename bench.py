@@ -40,7 +40,9 @@ KERNEL_NAMES = ["k_factorize<4, 8>", "k_factorize<4, 16>", "k_factorize<8, 16>",
                 "k_apply<2>", "k_apply<4>", "k_apply<8>", "k_apply<16>", "k_assemble",
                 "k_factorize_all", "k_apply_small", "k_apply_all", "k_round_all"]
 HEADLINE = "sparse3d:96"
-DECLARED_DEVICE_MEMORY = 200 * 2**30
+# device memory declared to the staging (cc->gpuMemorySize); BENCH_DEVICE_GIB overrides it, e.g. when ranks of a
+# rehearsal share one device
+DECLARED_DEVICE_MEMORY = int(float(os.environ.get("BENCH_DEVICE_GIB", "200")) * 2**30)
 T_START = time.perf_counter()
 
 
