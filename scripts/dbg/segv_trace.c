@@ -1,5 +1,7 @@
 /* Debug aid: loading this library installs a SIGSEGV handler that prints the native call stack
- * (module + offset per frame, for addr2line) to stderr and exits.  Load it with ctypes.CDLL. */
+ * (module + offset per frame, for addr2line) to stderr and exits.  Load it with ctypes.CDLL
+ * (tests/mgpu_worker.py does when MGPU_SEGV_TRACE names the built library).
+ *   gcc -shared -fPIC -O1 -o scripts/dbg/libsegv_trace.so scripts/dbg/segv_trace.c */
 #include <execinfo.h>
 #include <signal.h>
 #include <unistd.h>
