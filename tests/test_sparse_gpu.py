@@ -560,6 +560,25 @@ def test_h_kept_on_the_device_qtmult_and_solve(shape, leaf, nrhs):
     kept.close()
 
 
+@pytest.mark.parametrize("shape,leaf", [((14, 14), 3), ((6, 6, 6), 2)])
+def test_residual_of_the_factorization_itself_through_kept_h(shape, leaf):
+    """||A E - Q R|| / ||A|| with the device's own Q: the kept Householder vectors applied to the columns
+    of A E must reproduce R (Q'(A E) = [R; 0], of which the entry point returns the first n rows), so the
+    residual is formed without any other factorization in the loop.  Bar: 1e-12 in the Frobenius norm."""
+    A = problems.stacked_ls(shape)
+    sym = spqr.analyze(A, problems.nested_dissection(shape, leaf=leaf), relax=20, gpuMemorySize=2**34)
+    m, n = A.shape
+    assert n <= 256
+    kept = spqr.KeptFactorization(sym, A, nrhs=n)
+    AE = A[:, sym.Qfill[:n]].toarray()
+    QtAE = kept.qtmult(AE)                   # rows 0..n-1 of Q'(A E)
+    R = kept.R.toarray()
+    assert np.linalg.norm(QtAE - R) <= 1e-12 * np.linalg.norm(AE)
+    # and Q is orthogonal on these columns: the rows of Q'(A E) below n carry nothing, i.e. the norm is kept
+    assert abs(np.linalg.norm(QtAE) - np.linalg.norm(AE)) <= 1e-12 * np.linalg.norm(AE)
+    kept.close()
+
+
 def test_h_kept_refuses_what_it_cannot_serve():
     A = problems.stacked_ls((12, 12))
     Q = problems.nested_dissection((12, 12), leaf=3)
