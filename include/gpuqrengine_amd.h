@@ -83,7 +83,8 @@ typedef struct gpuqr_front
     /* Host copy of gpuRimap (size cm), optional, no counterpart in the reference's Front.  With it the
      * engine knows which rows of the parent each block of C rows lands in, sends the rows of C to the
      * parent as soon as they are final and lets the parent's first panels start while this front is
-     * still working on its later ones.  NULL: the parent waits for the whole front. */
+     * still working on its later ones.  It must hold exactly what gpuRimap holds (the engine orders
+     * the work by it and never compares the two).  NULL: the parent waits for the whole front. */
     const int32_t *cpuRimap;
 } gpuqr_front;
 

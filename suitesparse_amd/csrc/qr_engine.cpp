@@ -1398,9 +1398,10 @@ static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const 
                 // first row of C inside the front (when C lies inside it, which the engine cannot take for granted)
                 int64_t crow0 = -1 ;
                 const bool by_rows = pipelined && fr.cpuRimap != NULL ;
-                if (by_rows && !fr.push_only && !rows_done.empty ( ) && fr.gpuC >= fr.gpuF)
+                if (by_rows && !fr.push_only && !rows_done.empty ( ) && (uintptr_t) fr.gpuC >= (uintptr_t) fr.gpuF
+                    && ((uintptr_t) fr.gpuC - (uintptr_t) fr.gpuF) % sizeof (double) == 0)
                 {
-                    const int64_t off = (int64_t) (fr.gpuC - fr.gpuF) ;
+                    const int64_t off = (int64_t) (((uintptr_t) fr.gpuC - (uintptr_t) fr.gpuF) / sizeof (double)) ;
                     const int64_t r = off / front_pitch (fr) ;
                     const int64_t mn = std::min (fr.fm, fr.fn) ;
                     if (r + fr.cm <= mn) crow0 = r ;
