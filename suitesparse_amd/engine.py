@@ -45,6 +45,7 @@ class SparseMeta:
         self.gpuRjmap = 0       # device address
         self.gpuRimap = 0       # device address
         self.gpuC = 0           # device address
+        self.cpuRimap = None    # extension: host copy of gpuRimap (numpy int32), see gpuqr_front.cpuRimap
 
 
 class Front:
@@ -112,6 +113,10 @@ def _pack(fronts, keep):
         c.gpuS, c.Scount = _ptr(m.gpuS), m.Scount
         c.cm, c.cn, c.pn = m.cm, m.cn, m.pn
         c.gpuRjmap, c.gpuRimap, c.gpuC = _ptr(m.gpuRjmap), _ptr(m.gpuRimap), _ptr(m.gpuC)
+        if getattr(m, "cpuRimap", None) is not None:
+            ri = np.ascontiguousarray(m.cpuRimap, dtype=np.int32)
+            keep.append(ri)
+            c.cpuRimap = ri.ctypes.data
     return arr
 
 

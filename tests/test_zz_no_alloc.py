@@ -23,7 +23,7 @@ def _bind():
     return L
 
 
-def _sparse_batch(shape, leaf):
+def _sparse_batch(shape, leaf, with_map=False):
     """The fronts of a small multifrontal problem as one engine batch (S assembly, pack assembly,
     staircases), built from the C ABI's own assembly maps.  Returns (make, nbytes): make(buf) gives the
     Front list for a device arena of nbytes bytes."""
@@ -67,6 +67,8 @@ def _sparse_batch(shape, leaf):
                 m.pn = int(fn[pid])
                 m.gpuRjmap = dRj.data_ptr() + 4 * int(sym.RjmapOffsets[f])
                 m.gpuRimap = dRi.data_ptr() + 4 * int(sym.RimapOffsets[f])
+                if with_map:        # the host copy of the row map: contribution blocks then travel row block by row block
+                    m.cpuRimap = Rimap[int(sym.RimapOffsets[f]):int(sym.RimapOffsets[f]) + m.cm]
                 m.gpuC = fr.gpuF + 8 * (fr.rank * int(fn[f]) + int(fp[f]))
             fronts.append(fr)
         return fronts
@@ -137,6 +139,12 @@ def test_noalloc_matches_the_allocating_entry_point_twice_then_refuses_too_much(
     # and once more the first, to see that the smaller call left nothing behind that matters
     ref3, got3 = _both(L, make, torch.zeros(nwords, dtype=torch.float64, device=dev))
     assert np.array_equal(ref3, ref) and np.array_equal(got3, ref)
+
+    # the same batch with the host copies of the row maps (the parents then start on the rows their
+    # children have finished): another schedule, the same arithmetic, in both entry points
+    make_m, nwords_m, keep_m = _sparse_batch((24, 24), leaf=4, with_map=True)
+    ref_m, got_m = _both(L, make_m, torch.zeros(nwords_m, dtype=torch.float64, device=dev))
+    assert np.array_equal(ref_m, ref) and np.array_equal(got_m, ref)
 
     # beyond the fixed workspace: refused before anything is launched, the front is untouched
     m, n = 16384, 4096
