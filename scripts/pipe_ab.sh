@@ -2,9 +2,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out
 run () { # tag workload env...
   tag=$1; wl=$2; shift 2
-  env "$@" timeout -k 10 300 python bench.py --workload $wl --steps 5 --warmup 2 --extras none --no-cpu-baseline > $O/ab_$tag.json 2> $O/ab_$tag.err || exit 1
+  env "$@" timeout -k 10 300 python bench.py --workload $wl --steps 5 --warmup 2 --extras none --no-cpu-baseline > $O/ab_$tag.json 2> $O/ab_$tag.err || { tail -5 $O/ab_$tag.err; exit 1; }
   python3 -c "import json;d=json.loads(open('$O/ab_$tag.json').read().strip().splitlines()[-1]);print('$tag',round(d['ms_per_step'],1),round(d['kernel_ms_per_step'],1),d['launches_per_step'],round(d['cold_first_call_ms'],1))"
 }
-run st2_2d sparse2d:1024 GPUQR_STREAMS=2 && run st3_2d sparse2d:1024 GPUQR_STREAMS=3 &&
-run st3j0_2d sparse2d:1024 GPUQR_STREAMS=3 GPUQR_ASM_JOIN_BELOW=0 &&
-run st2_64 sparse3d:64 GPUQR_STREAMS=2 && run st3_64 sparse3d:64 GPUQR_STREAMS=3
+run g0_2d sparse2d:1024 GPUQR_GRAPH=0 && run g1_2d sparse2d:1024 GPUQR_GRAPH=1 GPUQR_VERBOSE=2 && grep "capture\|launch loop\|wait for" $O/ab_g1_2d.err | tail -4
