@@ -568,6 +568,13 @@ struct LaunchPlan
     int32_t nrounds = 0 ;
     int64_t nbuckets = 0, ntasks = 0, nrefs = 0 ;
     int64_t flops = 0 ;
+    void swap_with (LaunchPlan &o)
+    {
+        rptr.swap (o.rptr) ; bdep.swap (o.bdep) ; done_last.swap (o.done_last) ; bflops.swap (o.bflops) ; bbytes.swap (o.bbytes) ;
+        seg_ptr.swap (o.seg_ptr) ; seg_round.swap (o.seg_round) ;
+        std::swap (nrounds, o.nrounds) ; std::swap (nbuckets, o.nbuckets) ; std::swap (ntasks, o.ntasks) ;
+        std::swap (nrefs, o.nrefs) ; std::swap (flops, o.flops) ;
+    }
 } ;
 
 // The packed R of a front with at least QR_RSEG_MIN (4096) pivot rows leaves in pieces of QR_RSEG_COLS (512)
@@ -589,6 +596,8 @@ static void rseg_setup (void)
 #define QR_RSEG_COLS g_rseg_cols
 #define QR_RSEG_MIN  g_rseg_min
 
+#define QR_PLAN_SLOTS 4      // displaced schedules kept per device
+
 // bound on the launches left queued at a time: a checkpoint every QR_CK_EVERY launches, QR_CK_SLOTS of them in flight
 #define QR_CK_EVERY 512
 #define QR_CK_SLOTS 5
@@ -605,6 +614,19 @@ struct DeviceCache
     hipEvent_t evCheck [QR_CK_SLOTS][2] = {} ;  // checkpoints of the two compute streams that bound the queued launches
     void *d_tasks = NULL, *d_refs = NULL, *d_vt = NULL, *h_stage = NULL, *d_counters = NULL, *d_pack = NULL ;
     size_t cap_tasks = 0, cap_refs = 0, cap_vt = 0, cap_stage = 0, cap_counters = 0, cap_pack = 0 ;
+    // Schedules of earlier calls that another call has displaced, each with its own task and workgroup
+    // buffers on the device: a caller that alternates between a few problems (the stages of a staged
+    // factorization, the levels of a tree-mapped one: several calls per factorization, the same ones in
+    // every factorization) finds each of them again.  Their tasks point into the VT pool, which is
+    // shared: a schedule parked while the pool lay elsewhere is not taken back.
+    struct Parked
+    {
+        LaunchPlan lp ; uint64_t key = 0 ; int64_t nf = 0 ;
+        void *d_tasks = NULL, *d_refs = NULL, *vt_base = NULL ; size_t cap_tasks = 0, cap_refs = 0 ; uint64_t stamp = 0 ;
+    } ;
+    Parked parked [QR_PLAN_SLOTS] ;
+    void *plan_vt_base = NULL ;     // where the VT pool lay when the active schedule was staged
+    uint64_t stamp = 0 ;
     int num_cus = 0 ;
     char *scratch = NULL ;          // this device's copy of the fixed workspace (hipGetSymbolAddress), never freed
     size_t scratch_bytes = 0 ;
@@ -640,8 +662,51 @@ struct DeviceCache
         }
         return pool [k] ;
     }
+    // Make the schedule with this key the active one if it is here.  True: dc->lp, d_tasks, d_refs are its.
+    bool activate (uint64_t key, int64_t nf)
+    {
+        if (key == 0) return false ;
+        if (plan_key == key && plan_nf == nf && plan_vt_base == d_vt) return true ;
+        for (int i = 0 ; i < QR_PLAN_SLOTS ; i++)
+        {
+            Parked &q = parked [i] ;
+            if (q.key != key || q.nf != nf || q.vt_base != d_vt) continue ;
+            // swap the active schedule with the parked one
+            lp.swap_with (q.lp) ;
+            std::swap (plan_key, q.key) ; std::swap (plan_nf, q.nf) ;
+            std::swap (d_tasks, q.d_tasks) ; std::swap (d_refs, q.d_refs) ;
+            std::swap (cap_tasks, q.cap_tasks) ; std::swap (cap_refs, q.cap_refs) ;
+            std::swap (plan_vt_base, q.vt_base) ;
+            q.stamp = ++stamp ;
+            return true ;
+        }
+        return false ;
+    }
+    // The active schedule is about to be replaced: keep it aside if it is worth keeping.
+    void park_active ( )
+    {
+        if (plan_key == 0 || plan_vt_base != d_vt || d_tasks == NULL) { plan_key = 0 ; return ; }
+        int slot = 0 ;
+        for (int i = 0 ; i < QR_PLAN_SLOTS ; i++)
+        {
+            if (parked [i].key == 0 || parked [i].vt_base != d_vt) { slot = i ; break ; }
+            if (parked [i].stamp < parked [slot].stamp) slot = i ;
+        }
+        Parked &q = parked [slot] ;
+        // the slot's own buffers become the active ones (to be overwritten, grown if too small)
+        lp.swap_with (q.lp) ;
+        q.key = plan_key ; q.nf = plan_nf ; q.vt_base = plan_vt_base ; q.stamp = ++stamp ;
+        std::swap (d_tasks, q.d_tasks) ; std::swap (d_refs, q.d_refs) ;
+        std::swap (cap_tasks, q.cap_tasks) ; std::swap (cap_refs, q.cap_refs) ;
+        plan_key = 0 ; plan_nf = 0 ; plan_vt_base = NULL ;
+    }
     void release ( )
     {
+        for (int i = 0 ; i < QR_PLAN_SLOTS ; i++)
+        {
+            if (parked [i].d_tasks) (void) hipFree (parked [i].d_tasks) ;
+            if (parked [i].d_refs) (void) hipFree (parked [i].d_refs) ;
+        }
         if (sCompute) (void) hipStreamDestroy (sCompute) ;
         if (sApply) (void) hipStreamDestroy (sApply) ;
         if (sCopy) (void) hipStreamDestroy (sCopy) ;
@@ -1625,9 +1690,9 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
 
     // The caller vouches, by passing the same nonzero key, that nothing about the problem but the
     // values in the fronts has changed since the call that left its schedule on the device.
-    if (plan_key != 0 && dc->plan_key == plan_key && dc->plan_nf == nf && engine_mode ( ) != 1 && lp.ntasks > 0)
+    if (plan_key != 0 && engine_mode ( ) != 1 && dc->activate (plan_key, nf) && lp.ntasks > 0)
         return launch_rounds (dc, fronts, nf, stats, eng_verbose, eng_tlast) ;
-    dc->plan_key = 0 ;          // the device buffers are about to be overwritten
+    dc->park_active ( ) ;       // the active buffers are about to be overwritten: the schedule in them moves aside
 
     try
     {
@@ -1802,7 +1867,7 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
             lp.rptr.swap (sc.rptr) ; lp.bdep.swap (sc.bdep) ; lp.done_last.swap (sc.done_last) ;
             lp.seg_ptr.swap (sc.seg_ptr) ; lp.seg_round.swap (sc.seg_round) ;
             lp.nrounds = sc.nrounds ; lp.nbuckets = nbuckets ; lp.ntasks = ntasks ; lp.nrefs = nrefs ; lp.flops = plan.flops ;
-            dc->plan_key = plan_key ; dc->plan_nf = nf ;
+            dc->plan_key = plan_key ; dc->plan_nf = nf ; dc->plan_vt_base = dc->d_vt ;
             lp.bflops.swap (sc.bflops) ; lp.bbytes.swap (sc.bbytes) ;
             return launch_rounds (dc, fronts, nf, stats, eng_verbose, eng_tlast) ;
         }
