@@ -182,17 +182,21 @@ def _bind_subset(L):
 def _collect(sym, num, mine_c, want_R):
     """R blocks (copies) and the offsets of the leaving contribution blocks of a finished call."""
     Rblocks, Coff = {}, {}
-    fnn = np.diff(sym.Rp)
-    fpp = np.diff(sym.Super)
-    for f in np.nonzero(mine_c)[0]:
-        f = int(f)
-        if want_R:
+    nf = sym.nf
+    if want_R:
+        fnn = np.diff(sym.Rp)
+        fpp = np.diff(sym.Super)
+        stack = np.ctypeslib.as_array(num.Rstack, shape=(max(num.rsize, 1),))
+        for f in np.nonzero(mine_c)[0]:
+            f = int(f)
             rk = min(int(sym.Fm[f]), int(fpp[f]))
             size = rk * (rk + 1) // 2 + rk * (int(fnn[f]) - rk)
             off = num.Rblock[f]
-            Rblocks[f] = np.ctypeslib.as_array(num.Rstack, shape=(max(num.rsize, 1),))[off:off + size].copy()
-        if num.Cblock[f] >= 0:
-            Coff[f] = int(num.Cblock[f])
+            Rblocks[f] = stack[off:off + size].copy()
+    # (only a few of a call's fronts have a block that leaves it)
+    cblock = np.ctypeslib.as_array(num.Cblock, shape=(max(nf, 1),))[:nf]
+    for f in np.nonzero((cblock >= 0) & (np.asarray(mine_c[:nf]) != 0))[0]:
+        Coff[int(f)] = int(cblock[f])
     stats = dict(kernel_ms=float(num.gpuKernelTime), flops=int(num.gpuFlops), launches=int(num.gpuNumKernelLaunches),
                  groups=int(num.numStagesRun))
     return Rblocks, Coff, stats
@@ -285,20 +289,27 @@ def factorize_distributed(sym, A, factor_subset=None, gather_R=True, trace=None)
     wire = cdev if nccl else torch.device("cpu")        # where a tensor must live to be sent
 
     nf = sym.nf
-    owner, level = map_tree(sym, world)
     Parent = sym.Parent
     csc = A if (host_blocks or isinstance(A, _Csc)) else _Csc(A)
-    nlev = int(level.max()) + 1 if nf > 0 else 0
-    # fronts whose block leaves the call that makes it, by level
-    leaving = [[] for _ in range(nlev)]
-    for f in range(nf):
-        p = Parent[f]
-        if p < nf and (owner[p] != owner[f] or level[p] != level[f]):
-            leaving[level[f]].append(f)
-    info = dict(rank=rank, world=world, levels=nlev, calls=[],
-                n_cut=sum(1 for L in leaving for f in L if owner[Parent[f]] != owner[f]),
-                cut_bytes=8 * sum(_c_size(sym, f) for L in leaving for f in L if owner[Parent[f]] != owner[f]))
-    info.update(mapping_report(sym, owner, level, world))
+    # the map of the tree onto the ranks depends on the symbolic object and the number of ranks only:
+    # made once, kept with the object (a caller that factorizes again pays for the numeric work alone)
+    cache = sym.__dict__.setdefault("_rank_maps", {})
+    if world not in cache:
+        owner, level = map_tree(sym, world)
+        nlev = int(level.max()) + 1 if nf > 0 else 0
+        # fronts whose block leaves the call that makes it, by level
+        leaving = [[] for _ in range(nlev)]
+        for f in range(nf):
+            p = Parent[f]
+            if p < nf and (owner[p] != owner[f] or level[p] != level[f]):
+                leaving[level[f]].append(f)
+        static = dict(levels=nlev,
+                      n_cut=sum(1 for L in leaving for f in L if owner[Parent[f]] != owner[f]),
+                      cut_bytes=8 * sum(_c_size(sym, f) for L in leaving for f in L if owner[Parent[f]] != owner[f]))
+        static.update(mapping_report(sym, owner, level, world))
+        cache[world] = (owner, level, nlev, leaving, static)
+    owner, level, nlev, leaving, static = cache[world]
+    info = dict(rank=rank, world=world, calls=[], **static)
 
     held = {}           # front -> its contribution block, waiting here for the parent's call
     Rall = {}
@@ -307,11 +318,12 @@ def factorize_distributed(sym, A, factor_subset=None, gather_R=True, trace=None)
         Cout = {}
         trace("level %d: %d fronts" % (L, int(mine.sum())))
         if mine.any():
-            limbo = {}
-            for f in np.nonzero(mine)[0]:
-                for c in _children(sym, int(f)):
-                    if not mine[c]:
-                        limbo[c] = held[c]
+            # the blocks this call takes in: children of its fronts that another call made (kept with the map)
+            inc = cache.setdefault(("incoming", world, rank, L), None)
+            if inc is None:
+                inc = [c for f in np.nonzero(mine)[0] for c in _children(sym, int(f)) if not mine[c]]
+                cache[("incoming", world, rank, L)] = inc
+            limbo = {c: held[c] for c in inc}
             if host_blocks:
                 R, Cout, st = factor_subset(sym, csc, mine, limbo)
             else:
