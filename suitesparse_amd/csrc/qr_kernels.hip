@@ -805,6 +805,52 @@ extern "C" hipError_t qr_launch_copy_rows (const QrRowCopy *d_tasks, long long n
 }
 
 // -----------------------------------------------------------------------------
+// rank detection: 2-norms of column pieces
+// -----------------------------------------------------------------------------
+//
+// out [t] = || x_t ||_2 for the strided column piece of task t, one wave per task: the largest
+// magnitude first, then the sum of squares of the scaled entries (no overflow or underflow of the
+// squares, as dnrm2).  The pieces are the rows of dead pivot columns from their would-be pivot row
+// down: the norm SPQR's CPU path tests against its tolerance (SPQR/Source/spqr_front.cpp:418-424).
+
+__global__ void __launch_bounds__ (QR_THREADS) k_col_norms (const QrColNormTask *tasks, long long ntasks, double *out)
+{
+    const int lane = threadIdx.x & 63 ;
+    const long long t = (long long) blockIdx.x * (QR_THREADS / 64) + (threadIdx.x >> 6) ;
+    if (t >= ntasks) return ;                       // (whole waves leave; nobody waits for them)
+    const QrColNormTask task = tasks [t] ;
+    gcdouble *x = (gcdouble *) task.x ;
+    double big = 0 ;
+    int nan = 0 ;
+    for (long long i = lane ; i < task.nrows ; i += 64)
+    {
+        const double a = fabs (x [i * task.ld]) ;
+        nan |= (a != a) ;
+        big = fmax (big, a) ;
+    }
+    for (int s = 32 ; s > 0 ; s >>= 1) big = fmax (big, __shfl_xor (big, s, 64)) ;
+    nan = __any (nan) ;
+    double ssq = 0 ;
+    if (big > 0 && !nan)
+    {
+        const double inv = 1.0 / big ;
+        for (long long i = lane ; i < task.nrows ; i += 64) { const double v = x [i * task.ld] * inv ; ssq += v * v ; }
+        for (int s = 32 ; s > 0 ; s >>= 1) ssq += __shfl_xor (ssq, s, 64) ;
+    }
+    // a NaN in the piece gives a NaN (not "at or below" any tolerance), an infinity gives a NaN too (inf * 0)
+    if (lane == 0) ((gdouble *) out) [t] = nan ? __longlong_as_double (0x7ff8000000000000LL) : big * sqrt (ssq) ;
+}
+
+extern "C" hipError_t qr_launch_col_norms (const QrColNormTask *d_tasks, long long ntasks, double *d_out, hipStream_t stream)
+{
+    if (ntasks <= 0) return hipSuccess ;
+    const long long nb = (ntasks + QR_THREADS / 64 - 1) / (QR_THREADS / 64) ;
+    if (nb > 0x7fffffffLL) return hipErrorInvalidValue ;
+    hipLaunchKernelGGL (k_col_norms, dim3 ((unsigned) nb), dim3 (QR_THREADS), 0, stream, d_tasks, ntasks, d_out) ;
+    return hipGetLastError ( ) ;
+}
+
+// -----------------------------------------------------------------------------
 // kernels: one per task kind and row tier, so each gets its own register budget
 // -----------------------------------------------------------------------------
 

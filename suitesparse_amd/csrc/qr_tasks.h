@@ -105,6 +105,15 @@ struct QrRowCopy
     double       *dst;
 };
 
+// Rank detection: the piece of one front column whose 2-norm decides whether the column is dead
+// (rows [first, first + nrows) of a row-major front, one entry every `ld` doubles).
+struct QrColNormTask
+{
+    const double *x;            // first entry
+    int64_t       nrows;
+    int64_t       ld;
+};
+
 #define QR_QUEUE_HEAD   0       // counters[0]: next ticket
 #define QR_QUEUE_ERROR  1       // counters[1]: nonzero after a spin ran out (no task hangs the device)
 #define QR_QUEUE_FIRST  2       // counters[2 + c]: arrivals at counter c

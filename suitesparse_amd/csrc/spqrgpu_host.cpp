@@ -606,6 +606,8 @@ struct gpuqr_replay ;
 struct QrRowCopy { const double *src ; double *dst ; } ;        // = qr_tasks.h
 extern "C" hipError_t qr_launch_copy_rows (const QrRowCopy *d_tasks, long long ntasks, int ncols,
     long long sstride, long long dstride, hipStream_t stream) ;
+struct ColNormTask { const double *x ; int64_t nrows ; int64_t ld ; } ;       // = QrColNormTask of qr_tasks.h
+extern "C" hipError_t qr_launch_col_norms (const ColNormTask *d_tasks, long long ntasks, double *d_out, hipStream_t stream) ;
 
 // A factorization that keeps H (spqrgpu_amd_factorize_keep): the front arena with the Householder
 // vectors in place and a right-hand-side block of nrhs columns behind every front, the engine's
@@ -638,6 +640,9 @@ struct RankPlan
     hostvec<Long> colpos ;      // per front column (at Rp [f] + j): position in the permuted front
     hostvec<Long> rsize ;       // per front: entries of its squeezed, column-packed R block
     hostvec<Long> Stair ;       // staircases; full for touched fronts
+    // size n, filled by the pass that runs with this plan: for a column in `dead`, the 2-norm of its
+    // rows from the would-be pivot row down, i.e. the number the CPU rule compares with the tolerance
+    mutable hostvec<double> deadnorm ;
     void *d_findex = NULL, *d_Rjmap = NULL ;
     ~RankPlan ( ) { if (d_findex) (void) hipFree (d_findex) ; if (d_Rjmap) (void) hipFree (d_Rjmap) ; }
 } ;
@@ -1146,6 +1151,47 @@ static int factorize_impl
             for (size_t i = 0 ; i < used_dev.size ( ) ; i++) (void) hipFree (used_dev [i]) ;
             used_dev.clear ( ) ;
 
+            if (rp)
+            {
+                // ---- what the CPU rule would have seen in the columns this pass took for dead ------
+                // A dead pivot column k with g live pivot columns before it was tested on rows g.. of
+                // the front as they stood after those g columns.  Every reflector of this pass that
+                // came later worked on rows g.. only and left that norm alone; the last of them, the
+                // column's own at its position q in the permuted front, gathered what lay below row q
+                // into row q (the rows below hold its Householder vector now).  So the norm of rows
+                // g..q of the column in the reduced front is still that number, and the caller
+                // compares it with the tolerance.
+                hostvec<ColNormTask> ctasks ;
+                hostvec<Long> ccols ;
+                for (Long k = 0 ; k < numFronts ; k++)
+                {
+                    const Long f = list [k] ;
+                    if (!rp->touched [f]) continue ;
+                    const Long *pos = rp->colpos.data ( ) + Rp [f] ;
+                    walk_pivots (Fm [f], Super [f+1] - Super [f], Super [f], rp->dead.data ( ), [&] (Long kk, Long rm, bool)
+                    {
+                        if (!rp->dead [Super [f] + kk]) return ;
+                        ColNormTask ct ;
+                        ct.x = fronts [k].gpuF + rm * pitch [f] + pos [kk] ;
+                        ct.nrows = std::min (pos [kk] + 1, Fm [f]) - rm ; ct.ld = pitch [f] ;
+                        if (ct.nrows > 0) { ctasks.push_back (ct) ; ccols.push_back (Super [f] + kk) ; }
+                        else rp->deadnorm [Super [f] + kk] = 0 ;
+                    }) ;
+                }
+                const size_t nt = ctasks.size ( ) ;
+                if (nt > 0)
+                {
+                    hostvec<double> norms (nt) ;
+                    if (dTasks.ensure (nt * sizeof (ColNormTask)) != hipSuccess) { code = 1 ; goto done ; }
+                    if (dPrefix.ensure (nt * sizeof (double)) != hipSuccess) { code = 1 ; goto done ; }
+                    HIPCHK (hipMemcpyAsync (dTasks.p, ctasks.data ( ), nt * sizeof (ColNormTask), hipMemcpyHostToDevice, 0)) ;
+                    HIPCHK (qr_launch_col_norms ((const ColNormTask *) dTasks.p, (long long) nt, (double *) dPrefix.p, 0)) ;
+                    HIPCHK (hipMemcpyAsync (norms.data ( ), dPrefix.p, nt * sizeof (double), hipMemcpyDeviceToHost, 0)) ;
+                    HIPCHK (hipStreamSynchronize (0)) ;
+                    for (size_t i = 0 ; i < nt ; i++) rp->deadnorm [ccols [i]] = norms [i] ;
+                }
+            }
+
             // ---- R: packed on the device, one copy onto the stack ---------------------------------
             if (r_in_engine)
             {
@@ -1442,6 +1488,7 @@ static int build_rank_plan (const spqr_amd_symbolic *S, const char *dead, RankPl
     const spqr_amd_symbolic::NumericCache &NC = S->cache ;
     rp.dead.assign (dead, dead + std::max ((Long) 1, n)) ;
     rp.Rdead.assign ((size_t) std::max ((Long) 1, n), 0) ;
+    rp.deadnorm.assign ((size_t) std::max ((Long) 1, n), 0.0) ;
     rp.touched.assign ((size_t) std::max ((Long) 1, nf), 0) ;
     rp.live.assign ((size_t) std::max ((Long) 1, nf), 0) ;
     rp.rsize.assign ((size_t) std::max ((Long) 1, nf), 0) ;
@@ -1502,8 +1549,13 @@ static int build_rank_plan (const spqr_amd_symbolic *S, const char *dead, RankPl
 // ordinary factorization; the pivot columns whose diagonal of R is at or below tol are dead.  If there
 // are any, the fronts are factorized again with the dead columns moved out of the way (RankPlan), which
 // gives SPQR's squeezed R: rank rows, Rdead, dead columns holding the rows above their would-be pivot.
-// A pass that finds further dead columns is repeated with them; the set only grows, three passes at
-// most are expected for clear-cut deficiencies, eight are allowed.  tol < 0: no rank detection.
+// Every pass with a plan is checked against the CPU rule in both directions: a live pivot whose
+// diagonal entry is at or below tol is dead, and a dead column whose rows from its would-be pivot row
+// down have a norm above tol (k_col_norms) is alive after all -- the first pass spends a row on every
+// column, dead ones included, and can so starve the column after a dead one of the only row it had.
+// The passes end when a pass confirms every decision of its plan; decisions that confirm each other
+// in elimination order are the CPU rule's, which fixes each one from the earlier ones.  Two or three
+// passes for clear-cut deficiencies, twelve are allowed.  tol < 0: no rank detection.
 extern "C" int spqrgpu_amd_factorize_tol
 (
     const spqr_amd_symbolic *S, const int64_t *Ap, const int64_t *Ai, const double *Ax, double tol,
@@ -1519,10 +1571,12 @@ extern "C" int spqrgpu_amd_factorize_tol
     try
     {
         hostvec<char> dead ((size_t) std::max ((Long) 1, S->n), 0) ;
+        hostvec<char> revived ((size_t) std::max ((Long) 1, S->n), 0) ;
         Long passes = 1 ;
-        while (scan_diagonal (S, num, tol, dead.data ( )) > 0)
+        Long changed = scan_diagonal (S, num, tol, dead.data ( )) ;
+        while (changed > 0)
         {
-            if (passes >= 8) { spqr_amd_numeric_free (num) ; return 2 ; }
+            if (passes >= 12) { spqr_amd_numeric_free (num) ; return 2 ; }
             spqr_amd_numeric_free (num) ;
             num = NULL ;
             RankPlan rp ;
@@ -1530,6 +1584,19 @@ extern "C" int spqrgpu_amd_factorize_tol
             if (code == 0) code = factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, &rp, NULL, &num) ;
             if (code != 0) return code ;
             passes++ ;
+            // live columns that this pass shows to be dead ...
+            changed = scan_diagonal (S, num, tol, dead.data ( )) ;
+            // ... and dead ones that it shows to be alive: taken for dead because an earlier pass had
+            // spent a row on a dead column before them, a row the CPU rule leaves to the next column.
+            // A column comes back once; one that dies again sits at the tolerance to within rounding
+            // and stays dead.
+            for (Long j = 0 ; j < S->n ; j++)
+            {
+                if (rp.dead [j] && !revived [j] && !(rp.deadnorm [j] <= tol))
+                {
+                    dead [j] = 0 ; revived [j] = 1 ; changed++ ;
+                }
+            }
         }
         num->numPasses = passes ;
     }

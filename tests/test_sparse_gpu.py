@@ -478,10 +478,20 @@ def _rank_case(name):
         B[:, 4] = B[:, 2]
         B[:, 5] = -B[:, 2]
         return sp.csc_matrix(B), rng.permutation(45), None
+    if name == "row-left-by-a-dead-column":
+        # column 0 is negligible and column 1 lives in the one row that column 0 starts: a factorization
+        # that spends that row on column 0 finds nothing left of column 1, the CPU rule leaves the row
+        # to column 1; the duplicate of column 5 dies for good
+        B = np.zeros((40, 12))
+        B[:, 2:] = rng.uniform(-1, 1, size=(40, 10))     # (row 0 is dense: one front holds everything)
+        B[0, 0], B[0, 1] = 1e-30, 3.0
+        B[:, 6] = B[:, 5]
+        return sp.csc_matrix(B), None, 2
     raise KeyError(name)
 
 
-@pytest.mark.parametrize("name", ["config5-24", "zero-and-duplicate-columns", "wide", "config5-256"])
+@pytest.mark.parametrize("name", ["config5-24", "zero-and-duplicate-columns", "wide", "config5-256",
+                                  "row-left-by-a-dead-column"])
 def test_rank_detection_on_the_device_matches_the_cpu_rule(name):
     """Config 5: rank-deficient least squares at SPQR's default tolerance.  The device path
     (spqrgpu_amd_factorize_tol) must give the CPU rule's answer (the oracle restates
