@@ -135,6 +135,8 @@ typedef struct spqr_amd_numeric
     int64_t  csize;         /* subset driver: doubles of contribution blocks that left (in Cstack or the caller's device buffer) */
     int64_t  RstackBorrowed;/* 1: Rstack is the caller's memory (spqrgpu_amd_kernel) and is not freed with the object */
     int64_t  numPasses;     /* spqrgpu_amd_factorize_tol: factorization passes it took (1: no dead column found) */
+    double   norm_E_fro;    /* spqrgpu_amd_factorize_tol: 2-norm of the norms of the dead columns, what the CPU path
+                               leaves in QRnum->norm_E_fro and cc->SPQR_norm_E_fro (SPQR/Source/spqr_factorize.cpp:546-577) */
 } spqr_amd_numeric;
 
 /* Replaces void spqrgpu_kernel (spqr_blob <double> *Blob)

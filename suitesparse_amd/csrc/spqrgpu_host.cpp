@@ -1572,6 +1572,7 @@ extern "C" int spqrgpu_amd_factorize_tol
     {
         hostvec<char> dead ((size_t) std::max ((Long) 1, S->n), 0) ;
         hostvec<char> revived ((size_t) std::max ((Long) 1, S->n), 0) ;
+        double wscale = 0, wssq = 1 ;       // norm of the dead columns' norms, scaled as dnrm2 (spqr_front.cpp:431-451)
         Long passes = 1 ;
         Long changed = scan_diagonal (S, num, tol, dead.data ( )) ;
         while (changed > 0)
@@ -1597,8 +1598,17 @@ extern "C" int spqrgpu_amd_factorize_tol
                     dead [j] = 0 ; revived [j] = 1 ; changed++ ;
                 }
             }
+            wscale = 0 ; wssq = 1 ;
+            for (Long j = 0 ; j < S->n ; j++)
+            {
+                const double wk = rp.dead [j] ? rp.deadnorm [j] : 0 ;
+                if (!(wk > 0)) continue ;
+                if (wscale < wk) { const double rr = wscale / wk ; wssq = 1 + wssq * rr * rr ; wscale = wk ; }
+                else { const double rr = wk / wscale ; wssq += rr * rr ; }
+            }
         }
         num->numPasses = passes ;
+        num->norm_E_fro = wscale * sqrt (wssq) ;
     }
     catch (std::bad_alloc &)
     {

@@ -27,7 +27,7 @@ class Numeric(C.Structure):
                 ("numStagesRun", C.c_int64), ("assembleBytes", C.c_double),
                 ("Cstack", C.POINTER(C.c_double)), ("Cblock", C.POINTER(C.c_int64)),
                 ("RstackPinned", C.c_int64), ("csize", C.c_int64),
-                ("RstackBorrowed", C.c_int64), ("numPasses", C.c_int64)]
+                ("RstackBorrowed", C.c_int64), ("numPasses", C.c_int64), ("norm_E_fro", C.c_double)]
 
 
 _ARRAYS = ["Qfill", "PLinv", "Sleft", "Sp", "Sj", "Super", "Rp", "Rj", "Parent", "Childp", "Child",
@@ -159,6 +159,7 @@ def factorize(sym, A, want_R=True, tol=None):
     res.gpuNumKernelLaunches = int(num.gpuNumKernelLaunches)
     res.numStagesRun = int(num.numStagesRun)
     res.numPasses = int(num.numPasses)
+    res.norm_E_fro = float(num.norm_E_fro)
     res.assembleBytes = float(num.assembleBytes)
     L.spqr_amd_numeric_free(out)
     return res
