@@ -1,0 +1,64 @@
+// Drop-in translation unit for an SPQR build: the reference's entry point
+//
+//     void spqrgpu_computeFrontStaging (Long numFronts, Long *Parent, ..., cholmod_common *cc) ;
+//                                                                 (SPQR/Include/spqrgpu.hpp:16-57)
+//
+// implemented on libgpuqrengine_amd.so.  It replaces SPQR/SPQRGPU/spqrgpu_computeFrontStaging.cpp in
+// the list of SPQR's sources; spqr_analyze (SPQR/Source/spqr_analyze.cpp:1104-1111) calls it unchanged.
+// Compiled inside an SPQR tree with -DSUITESPARSE_HIP and -I<this repo>/include.
+//
+// This fork's signature carries the symbolic object as well (EXCLUDE_ALLOCATION_TIME, set in
+// SPQR/Include/spqr.hpp:11): its version allocates the engine's workspaces into QRsym here
+// (spqrgpu_computeFrontStaging.cpp:251-281) so that their allocation is not timed with the
+// factorization.  The AMD driver keeps its device workspaces per device between calls by itself, so
+// the pointers stay NULL and only the sizes are recorded.
+
+#ifdef SUITESPARSE_HIP
+
+#include "spqr.hpp"
+#include "spqrgpu_amd.h"
+
+void spqrgpu_computeFrontStaging
+(
+    Long numFronts, Long *Parent, Long *Childp, Long *Child,
+    Long *Fm, Long *Cm, Long *Rp, Long *Sp, Long *Sleft, Long *Super, Long *Post,
+    Long RimapSize, Long RjmapSize,
+    bool *feasible, Long *numStages, Long *Stagingp, Long *StageMap,
+    size_t *FSize, size_t *RSize, size_t *SSize,
+    Long *FOffsets, Long *ROffsets, Long *SOffsets,
+#ifdef EXCLUDE_ALLOCATION_TIME
+    spqr_symbolic *QRsym,
+#endif
+    cholmod_common *cc
+)
+{
+    *feasible = spqrgpu_amd_compute_front_staging (numFronts, Parent, Childp, Child, Fm, Cm, Rp, Sp,
+        Sleft, Super, Post, RimapSize, RjmapSize, cc->gpuMemorySize, numStages, Stagingp, StageMap,
+        FSize, RSize, SSize, FOffsets, ROffsets, SOffsets) != 0 ;
+    if (!*feasible)
+    {
+        // (the caller raises CHOLMOD_GPU_PROBLEM, spqr_analyze.cpp:1118-1126)
+        *numStages = 0 ;
+        return ;
+    }
+#ifdef EXCLUDE_ALLOCATION_TIME
+    Long fsize = 0, rsize = 0, ssize = 0, maxfronts = 0 ;
+    for (Long stage = 0 ; stage < *numStages ; stage++)
+    {
+        const Long leftover = spqrgpu_amd_numfronts_in_stage (stage, Stagingp, StageMap, Post, Child, Childp) ;
+        fsize = MAX (fsize, (Long) FSize [stage]) ;
+        rsize = MAX (rsize, (Long) RSize [stage]) ;
+        ssize = MAX (ssize, (Long) SSize [stage]) ;
+        maxfronts = MAX (maxfronts, Stagingp [stage+1] - Stagingp [stage] + leftover) ;
+    }
+    QRsym->wsMondoF_size = fsize ;
+    QRsym->wsMondoR_size = rsize ;
+    QRsym->wsS_size = ssize ;
+    QRsym->maxfronts_in_stage = maxfronts ;
+    QRsym->fronts [0] = QRsym->fronts [1] = NULL ;
+    QRsym->wsMondoF = QRsym->wsMondoR [0] = QRsym->wsMondoR [1] = NULL ;
+    QRsym->wsMondoS = QRsym->wsRimap = QRsym->wsRjmap = QRsym->wsS = NULL ;
+#endif
+}
+
+#endif

@@ -14,10 +14,21 @@
 #include <new>
 #include "gpuqrengine_amd.h"
 
+// Int is SuiteSparse_long.  The reference makes it a macro (GPUQREngine_Common.hpp:64), and so does this
+// fork's CHOLMOD/Include/cholmod_subtree.h:28-32 (as int, unless DLONG is set), which SuiteSparseQR.hpp
+// pulls in ahead of this header: such a macro is dropped here, as the reference's own redefinition does.
 #ifndef GPUQRENGINE_INT_DEFINED
 #define GPUQRENGINE_INT_DEFINED
+#ifdef Int
+#undef Int
+#endif
 typedef long Int ;                      // SuiteSparse_long
 #endif
+
+// SuiteSparse_GPURuntime's buffer class.  The engine has no use for it (a15: hipMalloc directly), but
+// this fork's spqr_symbolic keeps pointers to preallocated ones (SPQR/Include/SuiteSparseQR.hpp:208-219),
+// so the name must exist for that header to compile against this one.
+class Workspace ;
 #ifndef EMPTY
 #define EMPTY (-1)
 #endif
