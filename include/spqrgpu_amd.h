@@ -181,6 +181,27 @@ int spqrgpu_amd_factorize_keep (const spqr_amd_symbolic *sym, const int64_t *Ap,
                                 const double *Ax, int64_t nrhs,
                                 spqr_amd_numeric **num_out, spqr_amd_qt **qt_out);
 int spqrgpu_amd_qtmult (spqr_amd_qt *qt, const double *B, int64_t ldb, double *C, int64_t ldc);
+
+/* X = E (R \ C) by back substitution on the packed R blocks of num, on the host: the multifrontal part
+ * of spqr_rsolve (SPQR/Source/spqr_rsolve.cpp:136-338, keepH = 0, no singletons).  C is rank-by-nrhs
+ * (leading dimension ldc >= rank) in the row order of R, e.g. from spqrgpu_amd_qtmult, or the rows
+ * 0..rank-1 of the appended columns of R when B was appended to A (SPQR/Source/SuiteSparseQR.cpp:256-260);
+ * X is nacols-by-nrhs, leading dimension nacols; nacols <= n is the number of columns of A proper, later
+ * columns of the factorization are appended right-hand sides and are passed over.  Qfill (size >= nacols,
+ * "Qfill" of spqr_amd_symbolic_array) scatters the solution back to A's column order; NULL gives
+ * X = R \ C.  Dead pivot columns get zeros (the basic solution).  Returns 0, 1 out of memory,
+ * 3 invalid argument (including a numeric object that holds only a part of R). */
+int spqr_amd_rsolve (const spqr_amd_symbolic *sym, const spqr_amd_numeric *num, const int64_t *Qfill,
+                     int64_t nacols, int64_t nrhs, const double *C, int64_t ldc, double *X);
+
+/* min || A x - B ||_2 from a kept factorization: spqrgpu_amd_qtmult on the device, then spqr_amd_rsolve
+ * with the symbolic object's Qfill: what SuiteSparseQR_qmult (SPQR_QTX) followed by SuiteSparseQR_solve
+ * (SPQR_RETX_EQUALS_B) do on the reference's factorization object, on the CPU
+ * (SPQR/Source/SuiteSparseQR_expert.cpp:324-343).  B is m-by-nrhs (leading dimension ldb) with the nrhs
+ * given to spqrgpu_amd_factorize_keep, X n-by-nrhs (leading dimension n); sym must be the object the
+ * factorization was made with, from spqr_amd_analyze (it holds the column permutation). */
+int spqrgpu_amd_solve (spqr_amd_qt *qt, const spqr_amd_symbolic *sym, const spqr_amd_numeric *num,
+                       const double *B, int64_t ldb, double *X);
 int64_t spqr_amd_qt_rank (const spqr_amd_qt *qt);
 void spqr_amd_qt_free (spqr_amd_qt *qt);
 

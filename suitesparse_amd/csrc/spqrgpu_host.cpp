@@ -1790,6 +1790,112 @@ extern "C" int spqr_amd_rconvert
     return spqr_amd_rconvert_blocks (S, num->Rstack, num->Rblock, num->Rdead, Rcp, Ri, Rx) ;
 }
 
+// X = E (R \ C) on the packed R blocks, front by front from the last one back: the multifrontal part of
+// spqr_rsolve (SPQR/Source/spqr_rsolve.cpp:136-338 with keepH = false, no singletons).  C is rank-by-nrhs
+// (leading dimension ldc) in the row order of R, X is nacols-by-nrhs with leading dimension nacols.
+// Columns of the factorization from nacols on are right-hand sides that were appended to A and are
+// passed over (:264-267); dead pivot columns get the basic solution's zeros (:209-221); Qfill == NULL
+// gives X = R \ C.
+extern "C" int spqr_amd_rsolve
+(
+    const spqr_amd_symbolic *S, const spqr_amd_numeric *num, const int64_t *Qfill, int64_t nacols,
+    int64_t nrhs, const double *C, int64_t ldc, double *X
+)
+{
+    if (!S || !num || !num->Rstack || !num->Rblock || !num->Rdead || nrhs < 0 || nacols < 0 || nacols > S->n) return 3 ;
+    if (nrhs > 0 && (!C || !X)) return 3 ;
+    const Long nf = S->nf, n = nacols, rank = num->sumfrank ;
+    if (ldc < std::max ((Long) 1, rank)) return 3 ;
+    for (Long f = 0 ; f < nf ; f++) if (num->Rblock [f] < 0) return 3 ;      // a part of R lives elsewhere
+    try
+    {
+        const Long maxfrank = std::max ((Long) 1, num->maxfrank) ;
+        hostvec<const double *> Rcolp ((size_t) maxfrank) ;
+        hostvec<Long> Rlive ((size_t) maxfrank) ;
+        hostvec<double> W ((size_t) (maxfrank * std::max ((Long) 1, nrhs))) ;
+        for (Long kk = 0 ; kk < nrhs ; kk++) for (Long i = 0 ; i < n ; i++) X [i + kk * n] = 0 ;
+        const char *Rdead = num->Rdead ;
+        Long row2 = rank ;
+        for (Long f = nf - 1 ; f >= 0 ; f--)
+        {
+            const double *R = num->Rstack + num->Rblock [f] ;
+            const Long col1 = S->Super [f], fp = S->Super [f+1] - col1 ;
+            const Long pr = S->Rp [f], fn = S->Rp [f+1] - pr ;
+            // the live pivot columns of the block: one row of R each
+            Long rm = 0, k = 0 ;
+            for ( ; k < fp ; k++)
+            {
+                if (!Rdead [col1 + k])
+                {
+                    if (rm >= maxfrank) return 3 ;
+                    Rcolp [rm] = R ; Rlive [rm] = col1 + k ; rm++ ;
+                }
+                R += rm ;
+            }
+            const Long row1 = row2 - rm ;
+            if (row1 < 0) return 3 ;
+            // W = C (row1:row2-1, :)
+            for (Long kk = 0 ; kk < nrhs ; kk++)
+                for (Long i = 0 ; i < rm ; i++) W [i + kk * rm] = C [row1 + i + kk * ldc] ;
+            // W -= R2 x2: the columns right of the pivots, whose x is known from the fronts above
+            for ( ; k < fn ; k++)
+            {
+                const Long j = S->Rj [pr + k] ;
+                if (j >= n) break ;             // an appended right-hand side, and so are all further ones
+                const Long ii = Qfill ? Qfill [j] : j ;
+                if (!Rdead [j])
+                    for (Long kk = 0 ; kk < nrhs ; kk++)
+                    {
+                        const double xi = X [ii + kk * n] ;
+                        if (xi != 0) for (Long i = 0 ; i < rm ; i++) W [i + kk * rm] -= R [i] * xi ;
+                    }
+                R += rm ;
+            }
+            // the squeezed triangle
+            for (k = rm - 1 ; k >= 0 ; k--)
+            {
+                const double *Rk = Rcolp [k] ;
+                const Long j = Rlive [k] ;
+                if (j >= n) continue ;
+                const Long ii = Qfill ? Qfill [j] : j ;
+                for (Long kk = 0 ; kk < nrhs ; kk++)
+                {
+                    const double xi = W [k + kk * rm] / Rk [k] ;
+                    X [ii + kk * n] = xi ;
+                    if (xi != 0) for (Long i = 0 ; i < k ; i++) W [i + kk * rm] -= Rk [i] * xi ;
+                }
+            }
+            row2 = row1 ;
+        }
+        if (row2 != 0) return 3 ;
+    }
+    catch (std::bad_alloc &) { return 1 ; }
+    return 0 ;
+}
+
+// min || A x - B ||_2 from a kept factorization: X = E (R \ (Q'B)), Q'B on the device
+// (spqrgpu_amd_qtmult), the back substitution on the host (spqr_amd_rsolve).  What
+// SuiteSparseQR_solve (SPQR_RETX_EQUALS_B) composed with SuiteSparseQR_qmult (SPQR_QTX) gives on a
+// factorization object in the reference (SPQR/Source/SuiteSparseQR_expert.cpp), where both need the CPU.
+// B is m-by-nrhs with leading dimension ldb, nrhs the count given to spqrgpu_amd_factorize_keep;
+// X is n-by-nrhs with leading dimension n.
+extern "C" int spqrgpu_amd_solve
+(
+    spqr_amd_qt *qt, const spqr_amd_symbolic *S, const spqr_amd_numeric *num,
+    const double *B, int64_t ldb, double *X
+)
+{
+    if (!qt || !S || !num || !B || !X || qt->n != S->n || qt->m != S->m || (Long) S->Qfill.size ( ) < S->n) return 3 ;
+    if (num->sumfrank != qt->rank) return 3 ;
+    const Long rank = qt->rank, k = qt->nrhs ;
+    double *Cq = (double *) host_malloc ((size_t) std::max ((Long) 1, rank * k) * sizeof (double)) ;
+    if (!Cq) return 1 ;
+    int code = spqrgpu_amd_qtmult (qt, B, ldb, Cq, std::max ((Long) 1, rank)) ;
+    if (code == 0) code = spqr_amd_rsolve (S, num, S->Qfill.data ( ), S->n, k, Cq, std::max ((Long) 1, rank), X) ;
+    host_free (Cq) ;
+    return code ;
+}
+
 // -----------------------------------------------------------------------------
 // subtree driver: one process's share of the assembly tree
 // -----------------------------------------------------------------------------

@@ -107,7 +107,19 @@ def analyze(A, Q=None, relax=0, gpuMemorySize=0, rank_detection=False):
 
 
 class NumericResult:
-    pass
+    _num = None
+
+    def free(self):
+        """Release the numeric object kept by factorize(..., keep_num=True)."""
+        if self._num:
+            _bind().spqr_amd_numeric_free(self._num)
+            self._num = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def default_tol(A):
@@ -120,9 +132,10 @@ def default_tol(A):
     return float(L.spqr_amd_default_tol(A.shape[0], A.shape[1], _p(Ap), _p(Ax)))
 
 
-def factorize(sym, A, want_R=True, tol=None):
+def factorize(sym, A, want_R=True, tol=None, keep_num=False):
     """spqrgpu_amd_factorize, or spqrgpu_amd_factorize_tol when a tolerance is given
-    (+ spqr_amd_rconvert when want_R): returns R (scipy CSC, rank-by-n) and stats."""
+    (+ spqr_amd_rconvert when want_R): returns R (scipy CSC, rank-by-n) and stats.  With keep_num the
+    result keeps the numeric object (the packed R blocks) for rsolve(); release it with res.free()."""
     L = _bind()
     if hasattr(A, "Ap"):                # arrays already in the C ABI's types (multigpu._Csc)
         Ap, Ai, Ax = A.Ap, A.Ai, A.Ax
@@ -161,8 +174,33 @@ def factorize(sym, A, want_R=True, tol=None):
     res.numPasses = int(num.numPasses)
     res.norm_E_fro = float(num.norm_E_fro)
     res.assembleBytes = float(num.assembleBytes)
-    L.spqr_amd_numeric_free(out)
+    if keep_num:
+        res._num = out
+    else:
+        L.spqr_amd_numeric_free(out)
     return res
+
+
+def rsolve(sym, res, Cq, nacols=None, permute=True):
+    """spqr_amd_rsolve: X = E (R \\ Cq) by back substitution on the packed R blocks of a factorization
+    made with keep_num (SPQR/Source/spqr_rsolve.cpp:136-338).  Cq is rank-by-k in R's row order; columns
+    of the factorization from nacols on are appended right-hand sides and are passed over."""
+    L = _bind()
+    n = int(sym.n if nacols is None else nacols)
+    Cq = np.asarray(Cq, dtype=np.float64)
+    Cq = Cq.reshape(Cq.shape[0], -1)
+    rank, k = Cq.shape
+    Cf = np.zeros((max(rank, 1), max(k, 1)), order="F")
+    Cf[:rank, :k] = Cq
+    X = np.zeros((max(n, 1), max(k, 1)), order="F")
+    Qfill = _i64(sym.Qfill) if permute else None
+    L.spqr_amd_rsolve.restype = C.c_int
+    L.spqr_amd_rsolve.argtypes = [C.c_void_p, C.POINTER(Numeric), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                  C.c_int64, C.c_void_p]
+    code = L.spqr_amd_rsolve(sym._h, res._num, _p(Qfill) if permute else None, n, k, _p(Cf), max(rank, 1), _p(X))
+    if code != 0:
+        raise RuntimeError("spqr_amd_rsolve failed with code %d" % code)
+    return X[:n, :k].copy()
 
 
 def spqrgpu_computeFrontStaging(nf, Parent, Childp, Child, Fm, Cm, Rp, Sp, Sleft, Super, Post,
@@ -253,15 +291,16 @@ def qr_solve(A, B, Q=None, relax=0, gpuMemorySize=2**34):
     # R(0:n,0:n) is the factor of A(:,Q) only if the analysis kept B's columns behind all of A's
     if not np.array_equal(np.sort(sym.Qfill[:n]), np.arange(n)):
         raise RuntimeError("the appended right-hand sides were ordered among A's columns")
-    res = factorize(sym, AB)
-    R = res.R.tocsc()
-    if res.rank < n:
-        raise np.linalg.LinAlgError("A(:,Q) is structurally rank deficient on the GPU path (rank %d < %d)" % (res.rank, n))
-    R11 = R[:n, :n].tocsr()
-    Cq = R[:n, n:].toarray()
-    y = spsolve_triangular(R11, Cq, lower=False)
-    x = np.zeros((n, k))
-    x[sym.Qfill[:n]] = y                                   # R is the factor of A(:,Qfill)
+    res = factorize(sym, AB, keep_num=True)
+    try:
+        R = res.R.tocsc()
+        if res.rank < n:
+            raise np.linalg.LinAlgError("A(:,Q) is structurally rank deficient on the GPU path (rank %d < %d)" % (res.rank, n))
+        # rows 0..rank-1 of the appended columns are Q'B (and what lies below row n the residual's part);
+        # the back substitution runs on the packed blocks and passes over the appended columns
+        x = rsolve(sym, res, R[:, n:].toarray(), nacols=n)
+    finally:
+        res.free()
     return x, R, sym
 
 
@@ -336,7 +375,7 @@ class KeptFactorization:
         L.spqr_amd_rconvert(sym._h, out, _p(Rp), _p(Ri), _p(Rx))
         self.rank = int(out.contents.sumfrank)
         self.R = sp.csc_matrix((Rx[:Rp[n]], Ri[:Rp[n]], Rp), shape=(self.rank, n))
-        L.spqr_amd_numeric_free(out)
+        self._num = out                     # the packed R blocks: spqrgpu_amd_solve substitutes back on them
         L.spqr_amd_qt_rank.restype = C.c_int64
         L.spqr_amd_qt_rank.argtypes = [C.c_void_p]
         assert L.spqr_amd_qt_rank(self._qt) == self.rank
@@ -360,17 +399,24 @@ class KeptFactorization:
         return Cf[:self.rank, :k].copy()
 
     def solve(self, B):
-        """min ||A x - B||_2 for a full-column-rank A: x = E (R \\ (Q'B)), back substitution on the host
-        as spqr_rsolve does it in the reference (SPQR/Source/spqr_rsolve.cpp)."""
-        from scipy.sparse.linalg import spsolve_triangular
-        n = self.sym.n
-        if self.rank < n:
-            raise np.linalg.LinAlgError("rank %d < %d" % (self.rank, n))
-        Cq = self.qtmult(B)
-        y = spsolve_triangular(self.R.tocsr(), Cq, lower=False)
-        x = np.zeros_like(y)
-        x[self.sym.Qfill[:n]] = y
-        return x
+        """min ||A x - B||_2: x = E (R \\ (Q'B)) through spqrgpu_amd_solve: Q'B on the device, back
+        substitution on the packed R blocks on the host as spqr_rsolve does it in the reference
+        (SPQR/Source/spqr_rsolve.cpp).  A rank-deficient A gets the basic solution."""
+        L = _bind()
+        m, n = self.sym.m, self.sym.n
+        B = np.asarray(B, dtype=np.float64).reshape(m, -1)
+        k = B.shape[1]
+        if k > self.nrhs:
+            raise ValueError("more right-hand sides than the factorization was kept for")
+        Bf = np.zeros((m, self.nrhs), order="F")
+        Bf[:, :k] = B
+        X = np.zeros((max(n, 1), self.nrhs), order="F")
+        L.spqrgpu_amd_solve.restype = C.c_int
+        L.spqrgpu_amd_solve.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Numeric), C.c_void_p, C.c_int64, C.c_void_p]
+        code = L.spqrgpu_amd_solve(self._qt, self.sym._h, self._num, _p(Bf), m, _p(X))
+        if code != 0:
+            raise RuntimeError("spqrgpu_amd_solve failed with code %d" % code)
+        return X[:n, :k].copy()
 
     def close(self):
         if getattr(self, "_qt", None) and self._qt.value:
@@ -378,6 +424,9 @@ class KeptFactorization:
             L.spqr_amd_qt_free.argtypes = [C.c_void_p]
             L.spqr_amd_qt_free(self._qt)
             self._qt = C.c_void_p(0)
+        if getattr(self, "_num", None):
+            _bind().spqr_amd_numeric_free(self._num)
+            self._num = None
 
     def __del__(self):
         try:

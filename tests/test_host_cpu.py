@@ -343,3 +343,51 @@ def test_oracle_rank_detection_against_lapack():
     # without a tolerance nothing dies
     assert oracle.multifrontal_tol(sym, spqr.s_values(sym, A), -1.0)[2] == n
     _ = inv
+
+
+def test_rsolve_on_packed_blocks_without_a_gpu():
+    """spqr_amd_rsolve is host code: the packed R blocks of a CPU factorization (the oracle's fronts,
+    packed as SPQR's stack holds them) wrapped in a spqr_amd_numeric, C = R^-T (A Q)' b, and the back
+    substitution front by front must give the least-squares solution in A's column order; with Qfill
+    left out it gives it in R's column order."""
+    import ctypes as C
+    from scipy.sparse.linalg import spsolve_triangular
+    from mgpu_worker import oracle_factor_subset
+    from suitesparse_amd import multigpu
+    A = problems.stacked_ls((9, 9))
+    m, n = A.shape
+    sym = spqr.analyze(A, problems.nested_dissection((9, 9), leaf=3), relax=4, gpuMemorySize=2**33)
+    nf = sym.nf
+    Rb, _, _ = oracle_factor_subset(sym, A, np.ones(nf, bool), {})
+    R = multigpu.blocks_to_csc(sym, Rb)
+    num = spqr.Numeric()
+    Rblock = np.zeros(nf, np.int64)
+    off = 0
+    for f in range(nf):
+        Rblock[f] = off
+        off += Rb[f].size
+    Rstack = np.concatenate([Rb[f] for f in range(nf)])
+    Rdead = np.zeros(n, np.int8)
+    num.nf, num.rsize = nf, Rstack.size
+    num.Rstack = Rstack.ctypes.data_as(C.POINTER(C.c_double))
+    num.Rblock = Rblock.ctypes.data_as(C.POINTER(C.c_int64))
+    num.Rdead = Rdead.ctypes.data_as(type(num.Rdead))
+    num.sumfrank = n
+    num.maxfrank = int(max(min(int(sym.Fm[f]), int(sym.Super[f + 1] - sym.Super[f])) for f in range(nf)))
+
+    class Res:
+        _num = C.pointer(num)
+
+    rng = np.random.default_rng(2)
+    b = rng.standard_normal((m, 3))
+    AQ = A[:, sym.Qfill]
+    Cq = spsolve_triangular(R.T.tocsr(), AQ.T @ b, lower=True)
+    x = spqr.rsolve(sym, Res, Cq)
+    xl = np.linalg.lstsq(A.toarray(), b, rcond=None)[0]
+    assert np.abs(x - xl).max() <= 1e-11 * np.abs(xl).max()
+    y = spqr.rsolve(sym, Res, Cq, permute=False)
+    assert np.array_equal(y, x[sym.Qfill])
+    # a numeric object that holds only a part of R is refused
+    Rblock[nf // 2] = -1
+    with pytest.raises(RuntimeError):
+        spqr.rsolve(sym, Res, Cq)

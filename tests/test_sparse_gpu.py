@@ -573,6 +573,28 @@ def test_h_kept_on_the_device_qtmult_and_solve(shape, leaf, nrhs):
     kept.close()
 
 
+def test_basic_solution_of_a_rank_deficient_problem_on_the_packed_blocks():
+    """spqr_amd_rsolve on a squeezed R (SPQR/Source/spqr_rsolve.cpp:198-221: dead pivot columns get
+    zeros, the live ones are solved for): [A b] factorized with the default tolerance, b appended as the
+    reference's GPU path does; the live part of x must be the least-squares solution on the live
+    columns of A."""
+    A, Q, _ = _rank_case("zero-and-duplicate-columns")
+    A = sp.csc_matrix(A)
+    m, n = A.shape
+    b = np.random.default_rng(11).standard_normal((m, 2))
+    AB, Qab = spqr.append_rhs(A, b, Q)
+    sym = spqr.analyze(AB, Qab, relax=20, gpuMemorySize=2**34, rank_detection=True)
+    assert np.array_equal(np.sort(sym.Qfill[:n]), np.arange(n))
+    res = spqr.factorize(sym, AB, tol=spqr.default_tol(A), keep_num=True)
+    x = spqr.rsolve(sym, res, res.R.tocsc()[:, n:].toarray(), nacols=n)
+    dead_cols = sym.Qfill[:n][res.Rdead[:n] != 0]
+    res.free()
+    assert len(dead_cols) == 4 and np.all(x[dead_cols] == 0)
+    live = np.setdiff1d(np.arange(n), dead_cols)
+    xl = np.linalg.lstsq(A[:, live].toarray(), b, rcond=None)[0]
+    assert np.abs(x[live] - xl).max() <= 1e-10 * max(np.abs(xl).max(), 1.0)
+
+
 @pytest.mark.parametrize("shape,leaf", [((14, 14), 3), ((6, 6, 6), 2)])
 def test_residual_of_the_factorization_itself_through_kept_h(shape, leaf):
     """||A E - Q R|| / ||A|| with the device's own Q: the kept Householder vectors applied to the columns
