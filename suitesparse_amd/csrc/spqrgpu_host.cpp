@@ -1457,28 +1457,85 @@ extern "C" double spqr_amd_default_tol (int64_t m, int64_t n, const int64_t *Ap,
     return 20.0 * (double) (m + n) * 2.220446049250313e-16 * maxnorm ;
 }
 
-// Pivot columns of the factorization in `num` whose diagonal entry of R is at or below tol and that
-// are not yet in `dead`: flagged in `dead`, counted in the return value.  The R blocks are
-// column-packed, squeezed by the columns already dead.
-static Long scan_diagonal (const spqr_amd_symbolic *S, const spqr_amd_numeric *num, double tol, char *dead)
+// What a pass says about the plan it ran with (rp; NULL for the first pass, which takes every pivot
+// column for alive): decisions that must change are changed in `dead`, their number is returned; 0
+// means that the pass confirms its whole plan, which is then the CPU rule's.  The R blocks are
+// column-packed, squeezed by the plan's dead columns.
+//
+// The CPU rule (spqr_front.cpp:418-479) decides a column from the columns before it: those of its front
+// and, through the contribution blocks, those of the fronts below.  So in a front whose descendants
+// have all confirmed their plans the pass has done exactly what the rule does up to the first column
+// whose outcome contradicts the plan, and for those columns its numbers are the rule's numbers:
+// |R_kk| of a live column, and for a dead one the norm of its rows from the would-be pivot row down
+// (rp->deadnorm).  That first contradiction is settled for good.  If it is a live column that dies, at
+// row g say, the rule's numbers can be read a little further: it keeps testing rows g.. of the
+// following columns as long as they die too, every reflector the pass made since works inside rows
+// g.., so the norm of a column's entries from row g down to its own diagonal (to the bottom of the
+// front for a column that found no row left; plus what rp->deadnorm holds for a dead one) is the
+// number the rule tests.  A run of dead columns -- everything behind the last independent row of a
+// front, say -- is settled in one pass that way, and so is the first column that ends the run.
+// Behind that, and in fronts above a contradiction, the pass's numbers are not the rule's: there the
+// same tests only make guesses for the next plan (good ones for columns that depend on earlier
+// columns; a column guessed alive once is not guessed alive again, so guesses cannot chase each other
+// for ever), which a later pass settles.  Every pass that changes anything settles at least one more
+// column, so the passes end.
+static Long review_pass (const spqr_amd_symbolic *S, const spqr_amd_numeric *num, const RankPlan *rp,
+    double tol, char *dead, char *revived)
 {
-    Long found = 0 ;
-    for (Long f = 0 ; f < S->nf ; f++)
+    Long changed = 0 ;
+    const Long nf = S->nf ;
+    hostvec<char> clean ((size_t) std::max ((Long) 1, nf), 0) ;     // this pass confirmed the front and all below it
+    hostvec<Long> flips ;
+    auto norm_of = [] (const double *x, Long from, Long to, double extra)
+    {
+        double big = fabs (extra), ssq = 0 ;
+        for (Long i = from ; i < to ; i++) big = std::max (big, fabs (x [i])) ;
+        if (!(big > 0)) return big ;            // zero, or a NaN that the comparisons below treat as "not small"
+        for (Long i = from ; i < to ; i++) { const double v = x [i] / big ; ssq += v * v ; }
+        { const double v = extra / big ; ssq += v * v ; }
+        return big * sqrt (ssq) ;
+    } ;
+    for (Long f = 0 ; f < nf ; f++)             // postorder: children before parents
     {
         if (num->Rblock [f] < 0) continue ;
+        bool anchored = true ;
+        for (Long q = S->Childp [f] ; q < S->Childp [f+1] ; q++) anchored = anchored && clean [S->Child [q]] ;
         const double *R = num->Rstack + num->Rblock [f] ;
         const Long col1 = S->Super [f] ;
-        Long p = 0 ;
-        // (flags raised in this loop belong to the next pass: the walk must see the packing as it is)
-        hostvec<Long> hits ;
+        enum { EXACT, RUN, GUESS } phase = anchored ? EXACT : GUESS ;
+        Long p = 0, run_row = -1 ;
+        flips.clear ( ) ;
+        // (the walk must see the packing as it is: `dead` changes only after it)
         walk_pivots (S->Fm [f], S->Super [f+1] - col1, col1, dead, [&] (Long k, Long rm, bool live)
         {
+            const double *col = R + p ;         // the rm entries of this column: rows 0..rm-1
+            const Long j = col1 + k ;
             p += rm ;
-            if (live && fabs (R [p-1]) <= tol) hits.push_back (col1 + k) ;
+            if (dead [j])
+            {
+                // dead by the plan: it holds the rm rows above its would-be pivot row
+                const double below = rp ? rp->deadnorm [j] : 0 ;
+                if (phase == EXACT) { if (!(below <= tol)) { flips.push_back (j) ; phase = GUESS ; } }
+                else if (phase == RUN) { if (!(norm_of (col, run_row, rm, below) <= tol)) { flips.push_back (j) ; phase = GUESS ; } }
+                else if (!(below <= tol) && !revived [j]) { flips.push_back (j) ; revived [j] = 1 ; }
+                return ;
+            }
+            if (phase == EXACT)
+            {
+                if (live && fabs (col [rm-1]) <= tol) { flips.push_back (j) ; phase = RUN ; run_row = rm - 1 ; }
+            }
+            else if (phase == RUN)
+            {
+                if (norm_of (col, run_row, rm, 0.0) <= tol) flips.push_back (j) ;
+                else phase = GUESS ;
+            }
+            else if (live && fabs (col [rm-1]) <= tol) flips.push_back (j) ;
         }) ;
-        for (size_t i = 0 ; i < hits.size ( ) ; i++) { dead [hits [i]] = 1 ; found++ ; }
+        for (size_t i = 0 ; i < flips.size ( ) ; i++) dead [flips [i]] = !dead [flips [i]] ;
+        changed += (Long) flips.size ( ) ;
+        clean [f] = anchored && flips.empty ( ) ;
     }
-    return found ;
+    return changed ;
 }
 
 // The plan of a pass that knows the dead columns.  Returns 0, 1 (out of memory), 2 (device).
@@ -1546,16 +1603,14 @@ static int build_rank_plan (const spqr_amd_symbolic *S, const char *dead, RankPl
 
 // Numeric factorization with SPQR's rank detection (SPQR/Source/spqr_front.cpp:424-479), which the
 // reference leaves to its CPU path (spqr_analyze.cpp:106-125 turns the GPU off when tol >= 0).  First an
-// ordinary factorization; the pivot columns whose diagonal of R is at or below tol are dead.  If there
-// are any, the fronts are factorized again with the dead columns moved out of the way (RankPlan), which
-// gives SPQR's squeezed R: rank rows, Rdead, dead columns holding the rows above their would-be pivot.
-// Every pass with a plan is checked against the CPU rule in both directions: a live pivot whose
-// diagonal entry is at or below tol is dead, and a dead column whose rows from its would-be pivot row
-// down have a norm above tol (k_col_norms) is alive after all -- the first pass spends a row on every
-// column, dead ones included, and can so starve the column after a dead one of the only row it had.
-// The passes end when a pass confirms every decision of its plan; decisions that confirm each other
-// in elimination order are the CPU rule's, which fixes each one from the earlier ones.  Two or three
-// passes for clear-cut deficiencies, twelve are allowed.  tol < 0: no rank detection.
+// ordinary factorization; if it shows dead pivot columns, the fronts are factorized again with the dead
+// columns moved out of the way (RankPlan), which gives SPQR's squeezed R: rank rows, Rdead, dead columns
+// holding the rows above their would-be pivot.
+// Every pass is reviewed against the CPU rule in both directions (review_pass): live columns that must
+// die, dead ones that must come back -- the first pass spends a row on every column, dead ones
+// included, and can so starve the column after a dead one of the only row it had.  The passes end when
+// a pass confirms its whole plan, which is then the CPU rule's plan.  Two or three passes for clear-cut
+// deficiencies, 64 are allowed.  tol < 0: no rank detection.
 extern "C" int spqrgpu_amd_factorize_tol
 (
     const spqr_amd_symbolic *S, const int64_t *Ap, const int64_t *Ai, const double *Ax, double tol,
@@ -1573,11 +1628,12 @@ extern "C" int spqrgpu_amd_factorize_tol
         hostvec<char> dead ((size_t) std::max ((Long) 1, S->n), 0) ;
         hostvec<char> revived ((size_t) std::max ((Long) 1, S->n), 0) ;
         double wscale = 0, wssq = 1 ;       // norm of the dead columns' norms, scaled as dnrm2 (spqr_front.cpp:431-451)
+        const bool verbose = getenv ("GPUQR_VERBOSE") != NULL ;
         Long passes = 1 ;
-        Long changed = scan_diagonal (S, num, tol, dead.data ( )) ;
+        Long changed = review_pass (S, num, NULL, tol, dead.data ( ), revived.data ( )) ;
         while (changed > 0)
         {
-            if (passes >= 12) { spqr_amd_numeric_free (num) ; return 2 ; }
+            if (passes >= 64) { spqr_amd_numeric_free (num) ; return 2 ; }
             spqr_amd_numeric_free (num) ;
             num = NULL ;
             RankPlan rp ;
@@ -1585,18 +1641,18 @@ extern "C" int spqrgpu_amd_factorize_tol
             if (code == 0) code = factorize_impl (S, Ap, Ai, Ax, NULL, NULL, false, NULL, NULL, 0, &rp, NULL, &num) ;
             if (code != 0) return code ;
             passes++ ;
-            // live columns that this pass shows to be dead ...
-            changed = scan_diagonal (S, num, tol, dead.data ( )) ;
-            // ... and dead ones that it shows to be alive: taken for dead because an earlier pass had
-            // spent a row on a dead column before them, a row the CPU rule leaves to the next column.
-            // A column comes back once; one that dies again sits at the tolerance to within rounding
-            // and stays dead.
-            for (Long j = 0 ; j < S->n ; j++)
+            changed = review_pass (S, num, &rp, tol, dead.data ( ), revived.data ( )) ;
+            if (verbose)
             {
-                if (rp.dead [j] && !revived [j] && !(rp.deadnorm [j] <= tol))
-                {
-                    dead [j] = 0 ; revived [j] = 1 ; changed++ ;
-                }
+                Long nplan = 0, nnow = 0 ;
+                for (Long j = 0 ; j < S->n ; j++) { nplan += (rp.dead [j] != 0) ; nnow += (dead [j] != 0) ; }
+                fprintf (stderr, "  [spqrgpu] tolerance pass %ld: plan had %ld dead columns, %ld decisions changed, %ld dead now\n",
+                    (long) passes, (long) nplan, (long) changed, (long) nnow) ;
+                if (getenv ("GPUQR_VERBOSE") [0] == '2')
+                    for (Long j = 0 ; j < S->n ; j++)
+                        if ((rp.dead [j] != 0) != (dead [j] != 0))
+                            fprintf (stderr, "      column %ld: %s (norm %.3e, tol %.3e)\n", (long) j,
+                                dead [j] ? "dies" : "comes back", rp.dead [j] ? rp.deadnorm [j] : -1.0, tol) ;
             }
             wscale = 0 ; wssq = 1 ;
             for (Long j = 0 ; j < S->n ; j++)
