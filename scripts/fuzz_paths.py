@@ -1,0 +1,125 @@
+"""Randomised sweep of the other ways through the numeric driver, on the GPU: for random sparse
+full-column-rank problems (random ordering, amalgamation), the R of the one-stage factorization must
+come back (a) bit for bit from staged runs (declared memory 0 / small), (b) to rounding from the tree cut
+into pieces for 2-4 "ranks" that one process factorizes call by call (device or host blocks), (c) from
+a factorization that keeps H, whose Q'B and least-squares solutions are checked against LAPACK, and
+(d) from the appended-right-hand-side recipe.  Prints failures and a summary; exit code 1 on failure.
+
+    python scripts/fuzz_paths.py [cases] [first_seed]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from suitesparse_amd import multigpu, spqr     # noqa: E402
+
+COUNT = {"staged": 0, "pieces": 0, "kept": 0, "appended": 0}
+NMAX = int(os.environ.get("FUZZ_NMAX", "220"))
+
+
+def one_case(seed):
+    import torch
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(2, NMAX))
+    m = int(rng.integers(n, 3 * n + 8))
+    dens = float(rng.choice([0.01, 0.03, 0.08, 0.2]))
+    A = sp.random(m, n, density=dens, random_state=int(seed), format="lil")
+    A[np.arange(n), np.arange(n)] = 1.0 + rng.random(n)
+    A = sp.csc_matrix(A)
+    Q = rng.permutation(n) if rng.random() < 0.6 else None
+    relax = int(rng.choice([0, 4, 20]))
+    tag = "seed %d: %dx%d dens %.2f relax %d" % (seed, m, n, dens, relax)
+    fails = []
+    sym = spqr.analyze(A, Q, relax=relax, gpuMemorySize=2**34)
+    base = spqr.factorize(sym, A)
+    scale = np.abs(base.R).max()
+    # (a) staged runs
+    for mem in (0, 4_000_000):
+        try:
+            s2 = spqr.analyze(A, Q, relax=relax, gpuMemorySize=mem)
+        except RuntimeError:
+            continue
+        r2 = spqr.factorize(s2, A)
+        COUNT["staged"] += 1
+        if (r2.R != base.R).nnz != 0:
+            fails.append("%s: staged run (memory %d, %d stages) is not bit-identical: %.2e" % (
+                tag, mem, r2.numStagesRun, np.abs(r2.R - base.R).max() / scale))
+    # (b) the tree in pieces
+    parts = int(rng.integers(2, 5))
+    dev_blocks = bool(rng.random() < 0.5)
+    mem = int(rng.choice([0, 5_000_000, 2**34]))
+    try:
+        s3 = spqr.analyze(A, Q, relax=relax, gpuMemorySize=mem)
+    except RuntimeError:
+        s3 = sym
+    owner, level = multigpu.map_tree(s3, parts)
+    held, Rall = {}, {}
+    for L in range(int(level.max()) + 1 if s3.nf else 0):
+        for r in range(parts):
+            mine = (owner == r) & (level == L)
+            if not mine.any():
+                continue
+            limbo = {c: held[c] for f in np.nonzero(mine)[0] for c in multigpu._children(s3, int(f)) if not mine[c]}
+            if dev_blocks:
+                Rb, Cb, _ = multigpu.gpu_factor_subset_dev(s3, A, mine, limbo)
+                Cb = {f: t.clone() for f, t in Cb.items()}
+            else:
+                Rb, Cb, _ = multigpu.gpu_factor_subset(s3, A, mine, limbo)
+            held.update(Cb)
+            Rall.update(Rb)
+    torch.cuda.synchronize()
+    Rp = multigpu.blocks_to_csc(s3, Rall)
+    COUNT["pieces"] += 1
+    if Rp.shape != base.R.shape or not np.abs(Rp - base.R).max() <= 1e-12 * scale:
+        fails.append("%s: %d pieces (%s blocks, memory %d) differ from the whole tree" % (
+            tag, parts, "device" if dev_blocks else "host", mem))
+    # (c) H kept on the device
+    k = int(rng.integers(1, 6))
+    B = rng.standard_normal((m, k))
+    AQ = A[:, sym.Qfill].toarray()
+    if np.linalg.cond(AQ) < 1e8:
+        kept = spqr.KeptFactorization(sym, A, nrhs=k)
+        Qd, Rd = np.linalg.qr(AQ, mode="reduced")
+        # row signs: the device's R has a non-negative diagonal except where a column had nothing below
+        # its pivot (then the reflector is the identity and the pivot keeps its sign)
+        sgn = np.where(np.diag(Rd) * kept.R.diagonal()[:n] < 0, -1.0, 1.0)
+        Cq = kept.qtmult(B)
+        ref = (Qd * sgn).T @ B
+        COUNT["kept"] += 1
+        if not np.abs(Cq - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1.0):
+            fails.append("%s: Q'B from the kept factorization differs by %.2e" % (tag, np.abs(Cq - ref).max()))
+        x = kept.solve(B)
+        xl = np.linalg.lstsq(A.toarray(), B, rcond=None)[0]
+        if not np.abs(x - xl).max() <= 1e-7 * max(np.abs(xl).max(), 1.0):
+            fails.append("%s: solve from the kept factorization differs by %.2e" % (tag, np.abs(x - xl).max()))
+        kept.close()
+        # (d) appended right-hand sides
+        x2, _, _ = spqr.qr_solve(A, B, Q, relax=relax)
+        COUNT["appended"] += 1
+        if not np.abs(x2 - xl).max() <= 1e-7 * max(np.abs(xl).max(), 1.0):
+            fails.append("%s: solve with appended right-hand sides differs by %.2e" % (tag, np.abs(x2 - xl).max()))
+    return fails
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    t0, bad = time.time(), []
+    for s in range(first, first + cases):
+        f = one_case(s)
+        for line in f:
+            print("FAIL", line, flush=True)
+        bad += f
+        if (s - first) % 25 == 24:
+            print("... %d cases, %d failures, %.0f s" % (s - first + 1, len(bad), time.time() - t0), flush=True)
+    print("%d cases from seed %d: %d failures in %.0f s; checked: %s" % (cases, first, len(bad), time.time() - t0, COUNT))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -540,16 +540,38 @@ def test_randomised_sweep_of_both_numeric_paths():
     failed).  Seeds 5130 and 20557 are the two that the sweep first caught: a run of dead columns behind
     the last independent row of a wide front (two more found per pass, passes exhausted), and guesses
     that chased each other (a column left dead that the rule keeps)."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "scripts", "fuzz_parity.py"))
-    fz = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(fz)
+    fz = _load_script("fuzz_parity")
     fz.TOL_EVERY = 1
     bad = []
     for seed in [5130, 20557, 20848, 21067] + list(range(70000, 70150)):
         bad += fz.one_case(seed)
     assert not bad, bad[:5]
     assert fz.COUNT["tol"] >= 140 and fz.COUNT["tol_dead"] >= 100 and fz.COUNT["max_passes"] <= 12, fz.COUNT
+
+
+def _load_script(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "scripts", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_randomised_sweep_of_the_other_paths():
+    """scripts/fuzz_paths.py, a bounded run: staged runs bit-identical to the one-stage R, the tree in
+    pieces for 2-4 ranks (device or host blocks), Q'B and solves from a kept factorization, solves with
+    appended right-hand sides; scripts/fuzz_dense.py: dense batches against LAPACK, twice bit for bit,
+    and through the work-queue kernel."""
+    fz = _load_script("fuzz_paths")
+    bad = []
+    for seed in range(80000, 80060):
+        bad += fz.one_case(seed)
+    assert not bad, bad[:5]
+    assert fz.COUNT["staged"] >= 100 and fz.COUNT["pieces"] == 60 and fz.COUNT["kept"] >= 50, fz.COUNT
+    fd = _load_script("fuzz_dense")
+    for seed in range(80000, 80030):
+        bad += fd.one_case(seed)
+    assert not bad, bad[:5]
 
 
 def test_rank_detection_needs_its_analysis_and_costs_nothing_at_full_rank():
