@@ -2,8 +2,10 @@
 full-column-rank problems (random ordering, amalgamation), the R of the one-stage factorization must
 come back (a) bit for bit from staged runs (declared memory 0 / small), (b) to rounding from the tree cut
 into pieces for 2-4 "ranks" that one process factorizes call by call (device or host blocks), (c) from
-a factorization that keeps H, whose Q'B and least-squares solutions are checked against LAPACK, and
-(d) from the appended-right-hand-side recipe.  Prints failures and a summary; exit code 1 on failure.
+a factorization that keeps H, whose Q'B and least-squares solutions are checked against LAPACK,
+(d) from the appended-right-hand-side recipe, and (e) bit for bit through the binding an SPQR build
+uses (symbolic object from plain arrays, S's values in, R on the caller's stack).  One case in five is
+wide (pivots run out of rows; (c) and (d) are skipped there).  Prints failures and a summary; exit code 1 on failure.
 
     python scripts/fuzz_paths.py [cases] [first_seed]
 """
@@ -18,7 +20,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 from suitesparse_amd import multigpu, spqr     # noqa: E402
 
-COUNT = {"staged": 0, "pieces": 0, "kept": 0, "appended": 0}
+COUNT = {"staged": 0, "pieces": 0, "binding": 0, "kept": 0, "appended": 0}
 NMAX = int(os.environ.get("FUZZ_NMAX", "220"))
 
 
@@ -26,10 +28,12 @@ def one_case(seed):
     import torch
     rng = np.random.default_rng(seed)
     n = int(rng.integers(2, NMAX))
-    m = int(rng.integers(n, 3 * n + 8))
+    wide = bool(rng.random() < 0.2)             # more columns than rows: pivots run out of rows
+    m = int(rng.integers(max(1, n // 3), n)) if wide else int(rng.integers(n, 3 * n + 8))
     dens = float(rng.choice([0.01, 0.03, 0.08, 0.2]))
     A = sp.random(m, n, density=dens, random_state=int(seed), format="lil")
-    A[np.arange(n), np.arange(n)] = 1.0 + rng.random(n)
+    kd = min(m, n)
+    A[np.arange(kd), np.arange(kd)] = 1.0 + rng.random(kd)
     A = sp.csc_matrix(A)
     Q = rng.permutation(n) if rng.random() < 0.6 else None
     relax = int(rng.choice([0, 4, 20]))
@@ -78,6 +82,19 @@ def one_case(seed):
     if Rp.shape != base.R.shape or not np.abs(Rp - base.R).max() <= 1e-12 * scale:
         fails.append("%s: %d pieces (%s blocks, memory %d) differ from the whole tree" % (
             tag, parts, "device" if dev_blocks else "host", mem))
+    # (e) the binding an SPQR build uses: the symbolic object from plain arrays, S's values in, R on the caller's stack
+    sym_b = spqr.symbolic_from_arrays(s3)
+    out = spqr.spqrgpu_kernel(sym_b, spqr.s_values(s3, A))
+    COUNT["binding"] += 1
+    if out["code"] != 0:
+        fails.append("%s: spqrgpu_amd_kernel returned %d" % (tag, out["code"]))
+    else:
+        Rb = {f: out["stack"][out["Rblock"][f]:out["Rblock"][f] + multigpu._r_size(s3, f)] for f in range(s3.nf)}
+        Rk = multigpu.blocks_to_csc(s3, Rb)
+        if Rk.shape != base.R.shape or (Rk != base.R).nnz != 0:
+            fails.append("%s: R through the SPQR binding (memory %d) is not bit-identical" % (tag, mem))
+    if wide:
+        return fails
     # (c) H kept on the device
     k = int(rng.integers(1, 6))
     B = rng.standard_normal((m, k))

@@ -722,7 +722,8 @@ static int factorize_impl
     // its own beside the next group, which then packs its R into the other of two device blocks.
     std::thread r_thread ;
     hipError_t r_thread_err = hipSuccess ;
-    auto join_r = [&] ( ) { if (r_thread.joinable ( )) r_thread.join ( ) ; return r_thread_err ; } ;
+    const void *r_thread_src = NULL ;   // the device block the helper thread is copying out of
+    auto join_r = [&] ( ) { if (r_thread.joinable ( )) r_thread.join ( ) ; r_thread_src = NULL ; return r_thread_err ; } ;
     hostvec<gpuqr_front> fronts ;
     hostvec<double *> limbo ;           // contribution blocks waiting on the host for a later group
     hostvec<double *> limbo_dev ;       // ... or on the device, when it has the room (no PCIe round trip)
@@ -1217,6 +1218,10 @@ static int factorize_impl
                 if (dPrefix.ensure ((size_t) (numFronts + 1) * sizeof (long long)) != hipSuccess) { code = 1 ; goto done ; }
                 HIPCHK (hipMemcpyAsync (dTasks.p, ptasks.data ( ), (size_t) numFronts * sizeof (PackRTask), hipMemcpyHostToDevice, 0)) ;
                 HIPCHK (hipMemcpyAsync (dPrefix.p, prefix.data ( ), (size_t) (numFronts + 1) * sizeof (long long), hipMemcpyHostToDevice, 0)) ;
+                // The two device blocks take turns, and the copy of a stage is joined where the next stage starts
+                // its own -- which a stage without any R (fronts without rows) never does: the stage after it
+                // would then pack into the block that the helper thread is still reading.
+                if (r_thread_src == dR.p && join_r ( ) != hipSuccess) { code = 2 ; goto done ; }
                 HIPCHK (qr_launch_pack_r ((const QrPackRTask *) dTasks.p, (const long long *) dPrefix.p, (int) numFronts, prefix [numFronts], 0)) ;
                 if (rsum > 0 && num->RstackPinned)
                     HIPCHK (hipMemcpyAsync (num->Rstack + rhead, dR.p, (size_t) rsum * sizeof (double), hipMemcpyDeviceToHost, 0)) ;
@@ -1229,6 +1234,7 @@ static int factorize_impl
                     const size_t bytes = (size_t) rsum * sizeof (double) ;
                     if (g + 1 < ngroups && !rp && getenv ("GPUQR_SERIAL_R") == NULL)
                     {
+                        r_thread_src = src ;
                         r_thread = std::thread ([&WS, &r_thread_err, dst, src, bytes, wdev] ( )
                         {
                             r_thread_err = hipSetDevice (wdev) ;

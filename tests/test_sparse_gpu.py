@@ -459,6 +459,19 @@ def test_spqr_binding_from_arrays_gives_the_same_r(mem, pageable, monkeypatch):
     assert spqr.spqrgpu_kernel(sym2, spqr.s_values(sym, A), stack_room=sym.rnz - 1)["code"] == 1
 
 
+def test_stage_without_r_between_two_stages_in_a_fresh_process():
+    """One front per stage, pageable stack, fronts without rows among them (a wide matrix): the R of a
+    stage is copied out by a helper thread from one of two device blocks that take turns; a stage that
+    has no R never waited for that thread, and the stage after it packed into the block still being
+    read.  Only the first call of a process is slow enough to show it, hence the child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GPUQR_PAGEABLE_R="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dbg", "binding_race.py"), "10371", "5000000"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def _rank_case(name):
     rng = np.random.default_rng(17)
     if name == "config5-24":
