@@ -89,7 +89,10 @@ def one_case(seed):
             if a != b:
                 B[:, a] = B[:, b] * float(rng.choice([1.0, -2.0, 0.0]))
         B = sp.csc_matrix(B)
-        symr = spqr.analyze(B, Q, relax=relax, gpuMemorySize=2**34, rank_detection=True)    # (one stage: the tolerance path's own limit)
+        try:
+            symr = spqr.analyze(B, Q, relax=relax, gpuMemorySize=mem, rank_detection=True)
+        except RuntimeError:
+            symr = spqr.analyze(B, Q, relax=relax, gpuMemorySize=2**34, rank_detection=True)
         tol = spqr.default_tol(B)
         if tol > 0:
             try:
