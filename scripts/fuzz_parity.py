@@ -42,7 +42,49 @@ def borderline(B, sym, dead_dev, dead_cpu, tol):
     return abs(r - tol) <= noise
 
 
+def grid_tol_case(seed):
+    """A 2D grid least-squares problem of random size with duplicated and nearly duplicated columns
+    (BASELINE's rank-deficient configuration at random sizes), nested dissection, through the tolerance
+    path against the CPU rule's restatement."""
+    from suitesparse_amd import problems
+    rng = np.random.default_rng(seed)
+    k = int(rng.integers(6, 90))
+    n = k * k
+    ndup, nnear = int(rng.integers(0, max(1, n // 20))), int(rng.integers(0, max(1, n // 20)))
+    B, _, _ = problems.rank_deficient_ls(k, ndup, nnear, seed=seed)
+    Q = problems.nested_dissection((k, k), leaf=int(rng.integers(2, 9)))
+    relax = int(rng.choice([0, 4, 20]))
+    mem = int(rng.choice([0, 40_000_000, 2**34]))
+    tag = "seed %d: grid %dx%d with %d + %d dependent columns, relax %d mem %d" % (seed, k, k, ndup, nnear, relax, mem)
+    symr = spqr.analyze(B, Q, relax=relax, gpuMemorySize=mem, rank_detection=True)
+    if symr.numStages == 0:
+        symr = spqr.analyze(B, Q, relax=relax, gpuMemorySize=2**34, rank_detection=True)
+    tol = spqr.default_tol(B)
+    rr = spqr.factorize(symr, B, tol=tol)
+    Ro, Rdead_o, rank_o, _, normE = oracle.multifrontal_tol(symr, spqr.s_values(symr, B), tol)
+    COUNT["tol"] += 1
+    COUNT["tol_dead"] += int(rr.numPasses > 1)
+    COUNT["max_passes"] = max(COUNT["max_passes"], rr.numPasses)
+    COUNT["stages>1"] += int(rr.numStagesRun > 1)
+    if rr.rank != rank_o or not np.array_equal(rr.Rdead, Rdead_o):
+        return ["%s: rank %d vs %d, dead only on the device %s, only by the CPU rule %s" % (
+            tag, rr.rank, rank_o, np.nonzero(rr.Rdead > Rdead_o)[0][:8], np.nonzero(rr.Rdead < Rdead_o)[0][:8])]
+    Rs, Rs_o = rr.R.tocsc(), Ro.tocsc()
+    Rs.sort_indices()
+    Rs_o.sort_indices()
+    if not (np.array_equal(Rs.indptr, Rs_o.indptr) and np.array_equal(Rs.indices, Rs_o.indices)):
+        return ["%s: pattern of the squeezed R differs" % tag]
+    d = np.abs(np.abs(Rs.data) - np.abs(Rs_o.data)).max() / max(np.abs(Rs_o.data).max(), 1e-300) if Rs.nnz else 0.0
+    if not d <= 1e-10:
+        return ["%s: R differs by %.2e" % (tag, d)]
+    if abs(rr.norm_E_fro - normE) > 0.05 * tol:
+        return ["%s: norm_E_fro %.3e vs %.3e" % (tag, rr.norm_E_fro, normE)]
+    return []
+
+
 def one_case(seed):
+    if os.environ.get("FUZZ_GRID") is not None:
+        return grid_tol_case(seed)
     rng = np.random.default_rng(seed)
     n = int(rng.integers(1, NMAX))
     m = int(rng.integers(max(1, n // 2), 3 * n + 8))

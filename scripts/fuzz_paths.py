@@ -24,9 +24,27 @@ COUNT = {"staged": 0, "pieces": 0, "binding": 0, "kept": 0, "appended": 0}
 NMAX = int(os.environ.get("FUZZ_NMAX", "220"))
 
 
+GRID = os.environ.get("FUZZ_GRID") is not None      # grid least-squares problems of random shape instead
+
+
+def grid_case(rng):
+    from suitesparse_amd import problems
+    if rng.random() < 0.5:
+        shape = (int(rng.integers(3, 140)), int(rng.integers(3, 140)))
+    else:
+        shape = tuple(int(x) for x in rng.integers(2, 22, 3))
+    A = problems.stacked_ls(shape)
+    Q = problems.nested_dissection(shape, leaf=int(rng.integers(2, 9)))
+    return sp.csc_matrix(A), Q, "grid %s" % "x".join(map(str, shape))
+
+
 def one_case(seed):
     import torch
     rng = np.random.default_rng(seed)
+    if GRID:
+        A, Q, what = grid_case(rng)
+        relax = int(rng.choice([0, 4, 20]))
+        return run_paths(seed, rng, A, Q, relax, False, what)
     n = int(rng.integers(2, NMAX))
     wide = bool(rng.random() < 0.2)             # more columns than rows: pivots run out of rows
     m = int(rng.integers(max(1, n // 3), n)) if wide else int(rng.integers(n, 3 * n + 8))
@@ -37,17 +55,30 @@ def one_case(seed):
     A = sp.csc_matrix(A)
     Q = rng.permutation(n) if rng.random() < 0.6 else None
     relax = int(rng.choice([0, 4, 20]))
-    tag = "seed %d: %dx%d dens %.2f relax %d" % (seed, m, n, dens, relax)
+    return run_paths(seed, rng, A, Q, relax, wide, "dens %.2f" % dens)
+
+
+def run_paths(seed, rng, A, Q, relax, wide, what):
+    import torch
+    m, n = A.shape
+    tag = "seed %d: %dx%d %s relax %d" % (seed, m, n, what, relax)
     fails = []
     sym = spqr.analyze(A, Q, relax=relax, gpuMemorySize=2**34)
     base = spqr.factorize(sym, A)
     scale = np.abs(base.R).max()
+    AQs = A[:, sym.Qfill]
+    G = (AQs.T @ AQs)
+    E = abs(base.R.T @ base.R - G).max()
+    if not E <= 1e-11 * abs(G).max():
+        fails.append("%s: R'R differs from (AQ)'(AQ) by %.2e" % (tag, E))
     # (a) staged runs
-    for mem in (0, 4_000_000):
+    for mem in ((0, 4_000_000) if not GRID else (0, 30_000_000)):
         try:
             s2 = spqr.analyze(A, Q, relax=relax, gpuMemorySize=mem)
         except RuntimeError:
             continue
+        if s2.numStages == 0:
+            continue                            # a front does not fit the declared memory: infeasible, as in the reference
         r2 = spqr.factorize(s2, A)
         COUNT["staged"] += 1
         if (r2.R != base.R).nnz != 0:
@@ -56,11 +87,13 @@ def one_case(seed):
     # (b) the tree in pieces
     parts = int(rng.integers(2, 5))
     dev_blocks = bool(rng.random() < 0.5)
-    mem = int(rng.choice([0, 5_000_000, 2**34]))
+    mem = int(rng.choice([0, 5_000_000 if not GRID else 40_000_000, 2**34]))
     try:
         s3 = spqr.analyze(A, Q, relax=relax, gpuMemorySize=mem)
     except RuntimeError:
         s3 = sym
+    if s3.numStages == 0:
+        s3, mem = sym, 2**34
     owner, level = multigpu.map_tree(s3, parts)
     held, Rall = {}, {}
     for L in range(int(level.max()) + 1 if s3.nf else 0):
@@ -93,7 +126,7 @@ def one_case(seed):
         Rk = multigpu.blocks_to_csc(s3, Rb)
         if Rk.shape != base.R.shape or (Rk != base.R).nnz != 0:
             fails.append("%s: R through the SPQR binding (memory %d) is not bit-identical" % (tag, mem))
-    if wide:
+    if wide or n > 2500:
         return fails
     # (c) H kept on the device
     k = int(rng.integers(1, 6))
@@ -128,7 +161,10 @@ def main():
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     t0, bad = time.time(), []
     for s in range(first, first + cases):
-        f = one_case(s)
+        try:
+            f = one_case(s)
+        except RuntimeError as e:
+            f = ["seed %d: %s" % (s, e)]
         for line in f:
             print("FAIL", line, flush=True)
         bad += f
