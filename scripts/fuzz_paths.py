@@ -20,7 +20,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 from suitesparse_amd import multigpu, spqr     # noqa: E402
 
-COUNT = {"staged": 0, "pieces": 0, "binding": 0, "kept": 0, "appended": 0}
+COUNT = {"revalued": 0, "staged": 0, "pieces": 0, "binding": 0, "kept": 0, "appended": 0}
 NMAX = int(os.environ.get("FUZZ_NMAX", "220"))
 
 
@@ -71,6 +71,17 @@ def run_paths(seed, rng, A, Q, relax, wide, what):
     E = abs(base.R.T @ base.R - G).max()
     if not E <= 1e-11 * abs(G).max():
         fails.append("%s: R'R differs from (AQ)'(AQ) by %.2e" % (tag, E))
+    # (f) the same pattern with other values and back, through whatever the driver and the engine kept from
+    # the first call (maps, S permutation, schedule): 4 A gives 4 R (to rounding: the reciprocal and root
+    # seeds of the panel kernel are not exactly scale-invariant), and A again gives the first R bit for bit
+    r4 = spqr.factorize(sym, A * 4.0)
+    r5 = spqr.factorize(sym, A)
+    COUNT["revalued"] += 1
+    if not abs(r4.R - base.R * 4.0).max() <= 4e-12 * scale:
+        fails.append("%s: second factorization on the same symbolic object (values x 4) is not 4 R: %.2e" % (
+            tag, abs(r4.R - base.R * 4.0).max() / scale))
+    if (r5.R != base.R).nnz != 0:
+        fails.append("%s: third factorization (the first values again) differs from the first" % tag)
     # (a) staged runs
     for mem in ((0, 4_000_000) if not GRID else (0, 30_000_000)):
         try:
