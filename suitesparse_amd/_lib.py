@@ -5,6 +5,7 @@ is no fallback: if the library is missing, loading raises.
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPUQR_LIB_PATH") or os.path.join(_HERE, "lib", "libgpuqrengine_amd.so")
@@ -51,6 +52,16 @@ def lib():
         raise RuntimeError(
             "libgpuqrengine_amd.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
             % LIB_PATH)
+    # A PyTorch wheel brings its own copy of the HIP runtime (torch/lib/libamdhip64.so), the library is
+    # linked against the system's.  Whichever is loaded first serves the whole process, and PyTorch finds
+    # no device when it is not its own ("No HIP GPUs are available").  The tests, the benchmark and the
+    # multi-GPU driver use both, so PyTorch goes first here whenever it is installed; a C caller, or a
+    # Python process that sets GPUQR_NO_TORCH, never loads it.
+    if "torch" not in sys.modules and os.environ.get("GPUQR_NO_TORCH") is None:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     L.gpuqr_factor_dense.argtypes = [C.c_size_t, C.POINTER(FrontC), C.c_int64, C.POINTER(Stats)]
     L.gpuqr_factor_dense.restype = C.c_int
