@@ -1687,6 +1687,10 @@ static int engine_run (gpuqr_front *fronts, int64_t nf, gpuqr_stats *stats, uint
         plan_key = problem_fingerprint (fronts, nf) ;
         ENG_TICK ("fingerprint") ;
     }
+    // A schedule belongs to the mode it was made in: the engine's own choice between launches and the
+    // work queue (mode 2) must not be pre-empted by the launches that mode 0 left behind for the same
+    // problem, so the mode is part of every key.
+    if (plan_key != 0) plan_key = (plan_key ^ (0x9E3779B97F4A7C15ull * (uint64_t) (engine_mode ( ) + 1))) | 1 ;
 
     // The caller vouches, by passing the same nonzero key, that nothing about the problem but the
     // values in the fronts has changed since the call that left its schedule on the device.
