@@ -21,3 +21,15 @@ A[200:264, :] += np.sqrt(0.1) * np.eye(64)
 (R1,), _ = run_dense([A]); (R4,), _ = run_dense([A * 4.0])
 d = np.triu(R4[:64]) - 4.0 * np.triu(R1[:64])
 print("integer-like", "entries that differ:", int(np.count_nonzero(d)))
+from tests.util import stair_front
+for shape, ag in [((202, 153), 4), ((400, 150), 4), ((1200, 300), 8)]:
+    A = stair_front(shape[0], shape[1], rng, aggression=ag)
+    (R1,), _ = run_dense([A]); (R4,), _ = run_dense([A * 4.0])
+    k = min(shape)
+    d = np.triu(R4[:k]) - 4.0 * np.triu(R1[:k])
+    print("staircase", shape, "entries that differ:", int(np.count_nonzero(d)), "max rel %.2e" % (np.abs(d).max() / np.abs(R1).max()))
+# values spread over many magnitudes, as fronts deep in a tree have
+A = rng.uniform(-1, 1, size=(202, 153)) * 10.0 ** rng.integers(-8, 1, size=(202, 1))
+(R1,), _ = run_dense([A]); (R4,), _ = run_dense([A * 4.0])
+d = np.triu(R4[:153]) - 4.0 * np.triu(R1[:153])
+print("graded rows", "entries that differ:", int(np.count_nonzero(d)), "max rel %.2e" % (np.abs(d).max() / np.abs(R1).max()))
