@@ -188,7 +188,8 @@ def rsolve(sym, res, Cq, nacols=None, permute=True):
     L = _bind()
     n = int(sym.n if nacols is None else nacols)
     Cq = np.asarray(Cq, dtype=np.float64)
-    Cq = Cq.reshape(Cq.shape[0], -1)
+    if Cq.ndim == 1:
+        Cq = Cq[:, None]
     rank, k = Cq.shape
     Cf = np.zeros((max(rank, 1), max(k, 1)), order="F")
     Cf[:rank, :k] = Cq
