@@ -180,6 +180,73 @@ def test_failing_host_allocator_reaches_the_spqr_glue():
     assert (res.R != good.R).nnz == 0
 
 
+def test_failing_host_allocator_reaches_the_tolerance_path_and_the_back_substitution():
+    """The same for the passes of spqrgpu_amd_factorize_tol (plans, reviews, the host-packed R of
+    fronts with dead columns) and for spqr_amd_rsolve: out of memory (1) or the usual answer, never
+    anything else, and nothing left half-built."""
+    import scipy.sparse as sp
+    from suitesparse_amd import problems, spqr
+    L = _lib.lib()
+    MALLOC = C.CFUNCTYPE(C.c_void_p, C.c_size_t)
+    CALLOC = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_size_t)
+    FREE = C.CFUNCTYPE(None, C.c_void_p)
+    libc = C.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes = C.c_void_p, [C.c_size_t]
+    libc.calloc.restype, libc.calloc.argtypes = C.c_void_p, [C.c_size_t, C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    budget = {"n": 0}
+
+    def my_malloc(sz):
+        budget["n"] -= 1
+        return None if budget["n"] < 0 else libc.malloc(sz)
+
+    def my_calloc(a, b):
+        budget["n"] -= 1
+        return None if budget["n"] < 0 else libc.calloc(a, b)
+
+    cbs = (MALLOC(my_malloc), CALLOC(my_calloc), FREE(lambda p: libc.free(p)))
+    L.gpuqr_set_allocator.argtypes = [MALLOC, CALLOC, FREE]
+    A, _, _ = problems.rank_deficient_ls(12, 5, 4)
+    A = sp.csc_matrix(A)
+    Q = problems.nested_dissection((12, 12), leaf=3)
+    tol = spqr.default_tol(A)
+    good = spqr.factorize(spqr.analyze(A, Q, gpuMemorySize=2**33, rank_detection=True), A, tol=tol, keep_num=True)
+    assert good.numPasses >= 2 and good.rank < A.shape[1]
+    sym0 = spqr.analyze(A, Q, gpuMemorySize=2**33, rank_detection=True)
+    Cq = np.random.default_rng(1).standard_normal((good.rank, 2))
+    x_good = spqr.rsolve(sym0, good, Cq)
+    codes, rcodes = [], []
+    try:
+        for allowed in list(range(0, 120, 7)) + [10**6]:
+            sym = spqr.analyze(A, Q, gpuMemorySize=2**33, rank_detection=True)
+            budget["n"] = allowed
+            L.gpuqr_set_allocator(*cbs)
+            try:
+                res = spqr.factorize(sym, A, tol=tol)
+                codes.append(0)
+                assert res.rank == good.rank and np.array_equal(res.Rdead, good.Rdead) and (res.R != good.R).nnz == 0
+            except RuntimeError as e:
+                codes.append(int(str(e).split()[-1]))
+            finally:
+                L.gpuqr_set_allocator(MALLOC(0), CALLOC(0), FREE(0))
+        for allowed in (0, 1, 2, 3, 10**6):
+            budget["n"] = allowed
+            L.gpuqr_set_allocator(*cbs)
+            try:
+                x = spqr.rsolve(sym0, good, Cq)
+                rcodes.append(0)
+                assert np.array_equal(x, x_good)
+            except RuntimeError as e:
+                rcodes.append(int(str(e).split()[-1]))
+            finally:
+                L.gpuqr_set_allocator(MALLOC(0), CALLOC(0), FREE(0))
+    finally:
+        L.gpuqr_set_allocator(MALLOC(0), CALLOC(0), FREE(0))
+        good.free()
+    assert codes[0] == 1 and codes[-1] == 0 and set(codes) <= {0, 1}, codes
+    assert rcodes[0] == 1 and rcodes[-1] == 0 and set(rcodes) <= {0, 1}, rcodes
+
+
 def test_repeated_device_batches_reuse_the_schedule_and_follow_the_values():
     """The engine recognises a repeated problem description (same shapes, buffers, staircases) and
     replays its schedule; the factors must follow the new values, and a different batch in between
