@@ -25,7 +25,7 @@
 typedef long Int ;                      // SuiteSparse_long
 #endif
 
-// SuiteSparse_GPURuntime's buffer class.  The engine has no use for it (a15: hipMalloc directly), but
+// SuiteSparse_GPURuntime's buffer class.  The engine has no use for it (it calls hipMalloc directly), but
 // this fork's spqr_symbolic keeps pointers to preallocated ones (SPQR/Include/SuiteSparseQR.hpp:208-219),
 // so the name must exist for that header to compile against this one.
 class Workspace ;
