@@ -1,6 +1,6 @@
-"""The R of the direct driver and of the SPQR binding side by side for one seed of scripts/fuzz_paths.py."""
+"""The R of the direct driver and of the SPQR binding side by side for one seed of tests/sweeps/fuzz_paths.py."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 import numpy as np, scipy.sparse as sp
 from suitesparse_amd import multigpu, spqr
 seed = int(sys.argv[1])

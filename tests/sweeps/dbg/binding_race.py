@@ -3,10 +3,10 @@ must leave the same R on the caller's stack.  (The first call of a process is th
 thread that copies a stage's R out of a device block was still reading it when the stage after an
 R-less stage packed into the same block.)  Exit code 1 if the calls disagree.
 
-    [GPUQR_PAGEABLE_R=1] python scripts/dbg/binding_race.py seed declared_memory
+    [GPUQR_PAGEABLE_R=1] python tests/sweeps/dbg/binding_race.py seed declared_memory
 """
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 import numpy as np, scipy.sparse as sp
 from suitesparse_amd import multigpu, spqr
 seed, MEM = int(sys.argv[1]), int(sys.argv[2])

@@ -1,4 +1,4 @@
-"""Runs one seed of scripts/fuzz_parity.py (its failures printed in full)."""
+"""Runs one seed of tests/sweeps/fuzz_parity.py (its failures printed in full)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import fuzz_parity

@@ -1,7 +1,7 @@
-"""Where the tolerance path's R differs from the CPU rule's restatement, for one seed of scripts/fuzz_parity.py."""
+"""Where the tolerance path's R differs from the CPU rule's restatement, for one seed of tests/sweeps/fuzz_parity.py."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 import numpy as np, scipy.sparse as sp
 from oracle import oracle
 from suitesparse_amd import spqr

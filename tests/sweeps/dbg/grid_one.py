@@ -1,8 +1,8 @@
-"""One seed of the grid mode of scripts/fuzz_paths.py: which staged run fails, and how."""
+"""One seed of the grid mode of tests/sweeps/fuzz_paths.py: which staged run fails, and how."""
 import os, sys
 os.environ["FUZZ_GRID"] = "1"
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 import numpy as np
 import fuzz_paths
 from suitesparse_amd import spqr

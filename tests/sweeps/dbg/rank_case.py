@@ -1,7 +1,7 @@
 """Prints what the device's rank detection and the CPU rule's restatement give on one constructed case."""
 import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 import numpy as np, scipy.sparse as sp
 from suitesparse_amd import spqr
 from oracle import oracle

@@ -1,6 +1,6 @@
 """Which contribution blocks below the first non-scale-invariant front are themselves not exactly scaled?"""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 import numpy as np
 from suitesparse_amd import multigpu, problems, spqr
 shape, leaf, relax, front = (15, 15), 8, 0, 78

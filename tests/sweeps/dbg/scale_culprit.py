@@ -2,8 +2,8 @@
 whose contribution block is not; assemble that front on the host and push it through the dense entry
 point in both scalings."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 import numpy as np
 from suitesparse_amd import multigpu, problems, spqr
 from tests.test_dense_gpu import run_dense

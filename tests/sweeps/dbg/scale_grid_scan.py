@@ -1,6 +1,6 @@
 """Smallest grid problems for which R(4A) != 4 R(A) bit for bit through the sparse path."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 import numpy as np
 from suitesparse_amd import problems, spqr
 found = 0

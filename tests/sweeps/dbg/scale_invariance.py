@@ -1,7 +1,7 @@
 """Is R(4A) = 4 R(A) bit for bit?  Dense fronts of a few shapes, then a small grid problem front by front."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 import numpy as np
 from tests.test_dense_gpu import run_dense
 rng = np.random.default_rng(1)

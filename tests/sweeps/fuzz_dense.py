@@ -3,7 +3,7 @@ rows and columns, tall and wide, some with a staircase of leading zeros, row- or
 LAPACK (R'R = A'A, R up to row signs for full-rank tall fronts), the same batch twice (bit-identical),
 and through the persistent work-queue kernel (equal to rounding).  Exit code 1 on failure.
 
-    python scripts/fuzz_dense.py [cases] [first_seed]
+    python tests/sweeps/fuzz_dense.py [cases] [first_seed]
 """
 import os
 import sys
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from suitesparse_amd import _lib                                 # noqa: E402

@@ -4,7 +4,7 @@ dense batches, one after another in one process so that every call finds what th
 the fixed workspace; the reduced fronts must be equal bit for bit, and a batch beyond the workspace must
 be refused with GPUQR_TOOLARGE before anything runs.  Exit code 1 on failure.
 
-    python scripts/fuzz_noalloc.py [cases] [first_seed]
+    python tests/sweeps/fuzz_noalloc.py [cases] [first_seed]
 """
 import ctypes as C
 import os
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 from suitesparse_amd import _lib, engine                                  # noqa: E402
 from tests.test_zz_no_alloc import _bind, _dense_batch, _sparse_batch     # noqa: E402

@@ -4,7 +4,7 @@ with LAPACK's QR of A(:,Qfill) after row-sign normalisation; every few cases the
 dependent columns through the tolerance path, compared with the oracle's restatement of the CPU rule
 (rank, Rdead, R).  Prints one line per failure and a summary; exit code 1 if anything failed.
 
-    python scripts/fuzz_parity.py [cases] [first_seed]
+    python tests/sweeps/fuzz_parity.py [cases] [first_seed]
 """
 import os
 import sys
@@ -13,7 +13,7 @@ import time
 import numpy as np
 import scipy.sparse as sp
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 from oracle import oracle            # noqa: E402  (checker only)
 from suitesparse_amd import spqr     # noqa: E402

@@ -7,7 +7,7 @@ a factorization that keeps H, whose Q'B and least-squares solutions are checked 
 uses (symbolic object from plain arrays, S's values in, R on the caller's stack).  One case in five is
 wide (pivots run out of rows; (c) and (d) are skipped there).  Prints failures and a summary; exit code 1 on failure.
 
-    python scripts/fuzz_paths.py [cases] [first_seed]
+    python tests/sweeps/fuzz_paths.py [cases] [first_seed]
 """
 import os
 import sys
@@ -16,7 +16,7 @@ import time
 import numpy as np
 import scipy.sparse as sp
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 from suitesparse_amd import multigpu, spqr     # noqa: E402
 

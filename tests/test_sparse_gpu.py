@@ -467,7 +467,7 @@ def test_stage_without_r_between_two_stages_in_a_fresh_process():
     import subprocess
     import sys
     env = dict(os.environ, GPUQR_PAGEABLE_R="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dbg", "binding_race.py"), "10371", "5000000"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sweeps", "dbg", "binding_race.py"), "10371", "5000000"],
                        env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
@@ -546,7 +546,7 @@ def test_rank_detection_on_the_device_matches_the_cpu_rule(name):
 
 
 def test_randomised_sweep_of_both_numeric_paths():
-    """scripts/fuzz_parity.py, a bounded run: random sparse matrices (tall, wide, empty rows and columns),
+    """tests/sweeps/fuzz_parity.py, a bounded run: random sparse matrices (tall, wide, empty rows and columns),
     orderings, amalgamation and declared device memory through the numeric driver against LAPACK, and
     each one again with dependent columns through the tolerance path against the CPU rule's restatement
     (rank, Rdead, pattern, R'R on the live rows; decisions that rounding alone can tip are counted, not
@@ -564,16 +564,16 @@ def test_randomised_sweep_of_both_numeric_paths():
 
 def _load_script(name):
     import importlib.util
-    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "scripts", name + ".py"))
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tests", "sweeps", name + ".py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
 
 
 def test_randomised_sweep_of_the_other_paths():
-    """scripts/fuzz_paths.py, a bounded run: staged runs bit-identical to the one-stage R, the tree in
+    """tests/sweeps/fuzz_paths.py, a bounded run: staged runs bit-identical to the one-stage R, the tree in
     pieces for 2-4 ranks (device or host blocks), Q'B and solves from a kept factorization, solves with
-    appended right-hand sides; scripts/fuzz_dense.py: dense batches against LAPACK, twice bit for bit,
+    appended right-hand sides; tests/sweeps/fuzz_dense.py: dense batches against LAPACK, twice bit for bit,
     and through the work-queue kernel."""
     fz = _load_script("fuzz_paths")
     bad = []
