@@ -964,7 +964,9 @@ static int factorize_impl
         }
 
         // ---- arenas sized for the largest group, once ---------------------------------------------
-        const bool two_r = !num->RstackPinned && ngroups > 1 ;
+        // (a pageable stack and several groups: two device blocks for R take turns, so that a helper thread
+        // can copy one group's R out while the next group runs; given up when the device has no room for the second)
+        bool two_r = !num->RstackPinned && ngroups > 1 ;
         {
             Long fmax = 1, smax = 1, rmax [2] = {1, 1} ;
             for (Long g = 0 ; g < ngroups ; g++)
@@ -974,10 +976,23 @@ static int factorize_impl
                 Long &rm = rmax [(two_r && (g & 1)) ? 1 : 0] ;
                 rm = std::max (rm, rsum) ;
             }
-            if (dF.ensure ((size_t) fmax * sizeof (double)) != hipSuccess) { code = 1 ; goto done ; }
-            if (dS.ensure ((size_t) smax * sizeof (gpuqr_sentry)) != hipSuccess) { code = 1 ; goto done ; }
-            if (WS.dR.ensure ((size_t) rmax [0] * sizeof (double)) != hipSuccess) { code = 1 ; goto done ; }
-            if (two_r && WS.dR2.ensure ((size_t) rmax [1] * sizeof (double)) != hipSuccess) { code = 1 ; goto done ; }
+            auto need = [&] (Buf &b, size_t bytes, const char *what)
+            {
+                if (b.ensure (bytes) == hipSuccess) return true ;
+                (void) hipGetLastError ( ) ;
+                if (verbose) fprintf (stderr, "  [spqrgpu] no room on the device for %s (%.2f GB)\n", what, (double) bytes / 1e9) ;
+                return false ;
+            } ;
+            if (!need (dF, (size_t) fmax * sizeof (double), "the fronts of the largest group")) { code = 1 ; goto done ; }
+            if (!need (dS, (size_t) smax * sizeof (gpuqr_sentry), "the S entries of the largest group")) { code = 1 ; goto done ; }
+            if (two_r && (!need (WS.dR, (size_t) rmax [0] * sizeof (double), "the packed R of a group")
+                       || !need (WS.dR2, (size_t) rmax [1] * sizeof (double), "the second block of packed R")))
+            {
+                WS.dR2.release ( ) ;
+                two_r = false ;
+                rmax [0] = std::max (rmax [0], rmax [1]) ;
+            }
+            if (!two_r && !need (WS.dR, (size_t) rmax [0] * sizeof (double), "the packed R of the largest group")) { code = 1 ; goto done ; }
         }
         TICK ("workspace allocation") ;
 
