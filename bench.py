@@ -166,9 +166,9 @@ def rooflines(per_kernel, best, workload_tag):
                              "avg_launch_us": ka["ms"] * 1e3 / ka["launches"], "launches": ka["launches"],
                              "algorithmic_bytes_per_launch": ka["gbytes"] * 1e9 / ka["launches"],
                              "note": "many small launches beside the updates (contribution blocks travel 32 rows at a "
-                                     "time); their sum is 3 % of the kernel time; with whole-front hand-over "
-                                     "(GPUQR_NO_PIPELINE=1) the same bytes go in 353 launches at 2.28 TB/s, and "
-                                     "the step is 12 % longer"}
+                                     "time); their sum is 3 % of the kernel time at 96^3, where whole-front "
+                                     "hand-over (GPUQR_NO_PIPELINE=1) moves the same bytes in 353 launches at "
+                                     "2.28 TB/s and makes the step 12 % longer"}
     return roofline, roofline_assembly
 
 
