@@ -6,10 +6,19 @@
 // same conventions (placeholder front nf, Parent[nf] = -1, Sleft of size n+2,
 // front-local Sj, Fm/Cm without rank detection) - from A and a column
 // permutation alone, so that the numeric GPU path can run and be tested where
-// only this repository exists.  The supernode partition is the fundamental one
-// (optionally relaxed by merging a front into its parent when that adds few
-// explicit zeros); it is not CHOLMOD's, so front counts differ from an SPQR run
-// on the same matrix while every array stays self-consistent.
+// only this repository exists.  Two modes.  relax < 0: the arrays SPQR itself would
+// hold for the column order Quser (spqr_analyze called with SPQR_ORDERING_GIVEN, the
+// call spqr_1factor.cpp:624-641 makes after spqr_1colamd has ordered the columns):
+// no further postordering of the columns, fundamental supernodes and CHOLMOD's relaxed
+// amalgamation with its default parameters (CHOLMOD/Supernodal/cholmod_super_symbolic.c:
+// 590-760, nrelax 4/16/48, zrelax 0.8/0.1/0.05), the frontal tree postordered by front
+// width as spqr_analyze.cpp:561-580 does through cholmod_postorder; Super/Rp/Rj/Parent/
+// Post/Fm/Cm are then identical to an SPQR run's (tests/test_reference_parity_cpu.py
+// compares them with the reference compiled from its own sources).  relax >= 0: the
+// columns are postordered here, the partition is the fundamental one, optionally relaxed
+// by merging a front into its parent when that adds at most relax percent explicit
+// zeros; front counts then differ from an SPQR run while every array stays
+// self-consistent.
 
 #include <stdint.h>
 #include <stdlib.h>
@@ -75,6 +84,44 @@ static void tree_postorder (Long n, const Long *parent, Long *post)
     }
 }
 
+// Postorder of a forest with the children of a node visited in increasing order of weight,
+// ties in increasing node number; weights are clamped to [0, n-1] as CHOLMOD does
+// (CHOLMOD/Cholesky/cholmod_postorder.c:176-262): bucket lists by weight, filled in node order
+// and emptied from the heaviest bucket down, each node pushed on the front of its parent's list.
+static void weighted_postorder (Long n, const Long *parent, const Long *weight, Long *post)
+{
+    std::vector<Long> head (n, -1), next (n, -1), whead (n, -1), stack ;
+    for (Long j = 0 ; j < n ; j++)
+    {
+        const Long p = parent [j] ;
+        if (p < 0 || p >= n) continue ;
+        Long w = std::min (std::max (weight [j], (Long) 0), n - 1) ;
+        next [j] = whead [w] ;
+        whead [w] = j ;
+    }
+    for (Long w = n-1 ; w >= 0 ; w--)
+    {
+        for (Long j = whead [w], nj ; j != -1 ; j = nj)
+        {
+            nj = next [j] ;
+            next [j] = head [parent [j]] ;
+            head [parent [j]] = j ;
+        }
+    }
+    Long k = 0 ;
+    for (Long root = 0 ; root < n ; root++)
+    {
+        if (parent [root] != -1) continue ;
+        stack.push_back (root) ;
+        while (!stack.empty ( ))
+        {
+            const Long j = stack.back ( ), c = head [j] ;
+            if (c == -1) { post [k++] = j ; stack.pop_back ( ) ; }
+            else { head [j] = next [c] ; stack.push_back (c) ; }
+        }
+    }
+}
+
 // -----------------------------------------------------------------------------
 // the analysis
 // -----------------------------------------------------------------------------
@@ -101,6 +148,17 @@ extern "C" spqr_amd_symbolic *spqr_amd_analyze_rd
     spqr_amd_symbolic *S = NULL ;
     try
     {
+        if (Quser)
+        {
+            // a permutation of 0..n-1, or nothing is done
+            std::vector<char> seen (n, 0) ;
+            for (Long k = 0 ; k < n ; k++)
+            {
+                const Long c = Quser [k] ;
+                if (c < 0 || c >= n || seen [c]) { *status = 3 ; return NULL ; }
+                seen [c] = 1 ;
+            }
+        }
         S = new spqr_amd_symbolic ( ) ;
         { static std::atomic<uint64_t> next_uid (1) ; S->uid = next_uid.fetch_add (1) ; }
         S->m = m ; S->n = n ; S->anz = Ap [n] ;
@@ -111,14 +169,25 @@ extern "C" spqr_amd_symbolic *spqr_amd_analyze_rd
         std::vector<Long> parent0 (n), post (n) ;
         column_etree (m, n, Ap, Ai, Quser, parent0.data ( )) ;
         tree_postorder (n, parent0.data ( ), post.data ( )) ;
+        const bool cholmod_mode = (relax < 0) ;
         std::vector<Long> ipost (n), parent (n) ;
         for (Long k = 0 ; k < n ; k++) ipost [post [k]] = k ;
         S->Qfill.resize (n) ;
-        for (Long k = 0 ; k < n ; k++)
+        if (cholmod_mode)
         {
-            S->Qfill [k] = Quser ? Quser [post [k]] : post [k] ;
-            Long p = parent0 [post [k]] ;
-            parent [k] = (p == -1) ? -1 : ipost [p] ;
+            // the columns stay where the caller put them; post is used for the counts only
+            for (Long k = 0 ; k < n ; k++) S->Qfill [k] = Quser ? Quser [k] : k ;
+            parent = parent0 ;
+        }
+        else
+        {
+            for (Long k = 0 ; k < n ; k++)
+            {
+                S->Qfill [k] = Quser ? Quser [post [k]] : post [k] ;
+                Long p = parent0 [post [k]] ;
+                parent [k] = (p == -1) ? -1 : ipost [p] ;
+            }
+            for (Long k = 0 ; k < n ; k++) post [k] = k ;      // the columns are in postorder now
         }
         std::vector<Long> Qinv (n) ;
         for (Long k = 0 ; k < n ; k++) Qinv [S->Qfill [k]] = k ;
@@ -166,16 +235,18 @@ extern "C" spqr_amd_symbolic *spqr_amd_analyze_rd
         std::vector<Long> cc (n, 0) ;
         {
             std::vector<Long> first (n, -1), maxfirst (n, -1), prevleaf (n, -1), anc (n) ;
-            for (Long j = 0 ; j < n ; j++)
+            for (Long k = 0 ; k < n ; k++)
             {
-                // columns are in postorder: first[j] = first descendant of j
-                if (first [j] == -1) { first [j] = j ; cc [j] = 1 ; }
+                // first[j] = postorder rank of the first descendant of j
+                const Long j = post [k] ;
+                if (first [j] == -1) { first [j] = k ; cc [j] = 1 ; }
                 Long p = parent [j] ;
                 if (p != -1 && first [p] == -1) first [p] = first [j] ;
                 anc [j] = j ;
             }
-            for (Long j = 0 ; j < n ; j++)
+            for (Long k = 0 ; k < n ; k++)
             {
+                const Long j = post [k] ;
                 if (parent [j] != -1) cc [parent [j]]-- ;
                 for (Long row = S->Sleft [j] ; row < S->Sleft [j+1] ; row++)
                 {
@@ -198,7 +269,7 @@ extern "C" spqr_amd_symbolic *spqr_amd_analyze_rd
                 }
                 if (parent [j] != -1) anc [j] = parent [j] ;
             }
-            for (Long j = 0 ; j < n ; j++) if (parent [j] != -1) cc [parent [j]] += cc [j] ;
+            for (Long k = 0 ; k < n ; k++) { const Long j = post [k] ; if (parent [j] != -1) cc [parent [j]] += cc [j] ; }
         }
         S->ColCount = cc ;
 
@@ -224,10 +295,85 @@ extern "C" spqr_amd_symbolic *spqr_amd_analyze_rd
             fparent [f] = (p == -1) ? nf : col2front [p] ;
         }
 
+        // ---- CHOLMOD's relaxed amalgamation (cholmod_super_symbolic.c:676-790): supernode s+1 is
+        // merged into s when s+1 is the current parent of s and either the merged node has at most
+        // nrelax0 columns, or no zeros are added, or the fraction z of explicit zeros in the merged
+        // node passes the size-dependent thresholds ------------------------------------------
+        if (cholmod_mode && nf > 1)
+        {
+            const Long nrelax0 = 4, nrelax1 = 16, nrelax2 = 48 ;
+            const double zrelax0 = 0.8, zrelax1 = 0.1, zrelax2 = 0.05 ;
+            std::vector<Long> merged (nf, -1), nscol (nf), zeros (nf, 0), snz (nf) ;
+            std::vector<Long> sparent (nf) ;
+            for (Long f = 0 ; f < nf ; f++)
+            {
+                nscol [f] = super [f+1] - super [f] ;
+                snz [f] = cc [super [f]] ;
+                sparent [f] = (fparent [f] >= nf) ? -1 : fparent [f] ;
+            }
+            for (Long s = nf-2 ; s >= 0 ; s--)
+            {
+                if (sparent [s] == -1) continue ;
+                Long ss, snext ;
+                for (ss = sparent [s] ; merged [ss] != -1 ; ss = merged [ss]) ;
+                const Long cur = ss ;
+                for (ss = sparent [s] ; merged [ss] != -1 ; ss = snext) { snext = merged [ss] ; merged [ss] = cur ; }
+                if (cur != s+1) continue ;
+                const Long nscol0 = nscol [s], nscol1 = nscol [s+1], ns = nscol0 + nscol1 ;
+                Long totzeros = zeros [s+1] ;
+                const double lnz1 = (double) snz [s+1] ;
+                bool merge ;
+                if (ns <= nrelax0)
+                {
+                    merge = true ;
+                }
+                else
+                {
+                    const double lnz0 = (double) snz [s] ;
+                    const double xnewzeros = (double) nscol0 * (lnz1 + (double) nscol0 - lnz0) ;
+                    const Long newzeros = nscol0 * (snz [s+1] + nscol0 - snz [s]) ;
+                    if (xnewzeros == 0)
+                    {
+                        merge = true ;
+                    }
+                    else
+                    {
+                        const double xtotzeros = (double) totzeros + xnewzeros ;
+                        const double xns = (double) ns ;
+                        const double xtotsize = (xns * (xns+1) / 2) + xns * (lnz1 - (double) nscol1) ;
+                        const double z = xtotzeros / xtotsize ;
+                        totzeros += newzeros ;
+                        merge = ((ns <= nrelax1 && z < zrelax0) || (ns <= nrelax2 && z < zrelax1) || (z < zrelax2))
+                            && (xtotsize < (double) INT64_MAX / sizeof (double)) ;
+                    }
+                }
+                if (merge)
+                {
+                    zeros [s] = totzeros ;
+                    merged [s+1] = s ;
+                    snz [s] = nscol0 + snz [s+1] ;
+                    nscol [s] += nscol [s+1] ;
+                }
+            }
+            std::vector<Long> newsuper ;
+            for (Long f = 0 ; f < nf ; f++) if (merged [f] == -1) newsuper.push_back (super [f]) ;
+            newsuper.push_back (n) ;
+            const Long nf2 = (Long) newsuper.size ( ) - 1 ;
+            super.swap (newsuper) ;
+            nf = nf2 ;
+            for (Long f = 0 ; f < nf ; f++) for (Long j = super [f] ; j < super [f+1] ; j++) col2front [j] = f ;
+            fparent.assign (nf, nf) ;
+            for (Long f = 0 ; f < nf ; f++)
+            {
+                const Long p = parent [super [f+1] - 1] ;
+                fparent [f] = (p == -1) ? nf : col2front [p] ;
+            }
+        }
+
         // ---- relaxed amalgamation: merge a front into its parent when it is the parent's
         // last child in column order (so the pivot ranges stay contiguous) and the merged
         // front gains at most `relax` percent explicit zeros ----------------------------
-        if (relax > 0 && nf > 1)
+        if (!cholmod_mode && relax > 0 && nf > 1)
         {
             // sizes: fp[f], fn[f] = cc of first column.  Merging child c (last columns end at
             // super[p]) into parent p gives fp = fpc + fpp, fn = fpc + fnp (needs struct(c) minus
@@ -302,6 +448,7 @@ extern "C" spqr_amd_symbolic *spqr_amd_analyze_rd
         }
         S->Post.resize (nf+1) ;
         for (Long f = 0 ; f <= nf ; f++) S->Post [f] = f ;     // fronts are numbered in postorder
+        // (in the CHOLMOD mode Post and the child lists are redone below, once the widths are known)
 
         // ---- front patterns Rp, Rj ------------------------------------------------------
         S->Rp.assign (nf+1, 0) ;
@@ -337,6 +484,23 @@ extern "C" spqr_amd_symbolic *spqr_amd_analyze_rd
         }
         S->rjsize = (Long) S->Rj.size ( ) ;
 
+        if (cholmod_mode)
+        {
+            // the frontal tree postordered with the children of a front in increasing order of
+            // their width, the placeholder root last; child lists in that order
+            // (spqr_analyze.cpp:561-611)
+            std::vector<Long> weight (nf+1) ;
+            for (Long f = 0 ; f < nf ; f++) weight [f] = S->Rp [f+1] - S->Rp [f] ;
+            weight [nf] = 1 ;
+            weighted_postorder (nf+1, S->Parent.data ( ), weight.data ( ), S->Post.data ( )) ;
+            std::vector<Long> w (S->Childp.begin ( ), S->Childp.begin ( ) + nf + 1) ;
+            for (Long kf = 0 ; kf < nf ; kf++)
+            {
+                const Long c = S->Post [kf] ;
+                S->Child [w [S->Parent [c]]++] = c ;
+            }
+        }
+
         // ---- Fm, Cm, map offsets, front-local Sj, flop count ----------------------------
         // (spqr_analyze.cpp:646-902 with do_rank_detection = false)
         S->Fm.assign (nf+1, 0) ; S->Cm.assign (nf+1, 0) ;
@@ -345,8 +509,9 @@ extern "C" spqr_amd_symbolic *spqr_amd_analyze_rd
         S->maxfn = 0 ; S->flopcount = 0 ; S->rnz = 0 ;
         {
             std::vector<Long> Fmap (n, -1), Stair ;
-            for (Long f = 0 ; f < nf ; f++)
+            for (Long kf = 0 ; kf < nf ; kf++)
             {
+                const Long f = S->Post [kf] ;
                 const Long col1 = super [f], col2 = super [f+1] ;
                 const Long p1 = S->Rp [f], p2 = S->Rp [f+1] ;
                 const Long fp = col2 - col1, fn = p2 - p1 ;
