@@ -29,6 +29,11 @@ def lib():
     if _lib is None:
         if not available():
             raise RuntimeError("oracle/_ref/libspqr_ref.so is not built (oracle/build_ref.sh needs /root/reference)")
+        # The library is linked with GNU OpenMP; MKL's run-time layer must be told to thread through the
+        # same runtime.  Left to its default (Intel's) in a process that already holds libgomp (torch
+        # does), dlarfb returns wrong numbers without any error: seen as an R that differed from row
+        # 907 on in a 1000-column problem.
+        os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
         _lib = C.CDLL(_SO)
         _lib.ref_open.restype = C.c_void_p
         _lib.ref_open.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int]

@@ -1,0 +1,100 @@
+"""Comparisons with the REFERENCE's own CPU SuiteSparseQR, run live through oracle/_ref/libspqr_ref.so
+(oracle/build_ref.sh compiles it from the reference's sources where they lie; the built library
+travels with the tree, the reference does not).  No reference output is stored in the repository:
+every test that uses this module runs the reference on generated inputs and compares on the spot."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import ref
+from suitesparse_amd import problems
+
+ORD_FIXED, ORD_COLAMD, ORD_AMD, ORD_METIS = 0, 2, 5, 6
+NO_TOL, DEFAULT_TOL = -1.0, -2.0
+SYM_ARRAYS = ("Super", "Rp", "Rj", "Parent", "Post", "Childp", "Child", "Sp", "Sleft", "PLinv", "Qfill")
+
+needs_reference = pytest.mark.skipif(not ref.available(), reason="oracle/_ref/libspqr_ref.so is not built")
+
+
+def ash219_standin():
+    """219 x 85 0/1 matrix with two entries per row, seed 219 (the collection's ash219 is not in the
+    reference tree)."""
+    rng = np.random.default_rng(219)
+    rows = np.repeat(np.arange(219), 2)
+    cols = np.concatenate([rng.choice(85, size=2, replace=False) for _ in range(219)])
+    return sp.csc_matrix((np.ones(438), (rows, cols)), shape=(219, 85))
+
+
+def matrix(name):
+    kind, arg = name.split(":")
+    if kind == "grid":
+        return problems.stacked_ls(tuple(int(x) for x in arg.split("x")))
+    if kind == "rankdef":
+        k, nd, nn = (int(x) for x in arg.split("x"))
+        return problems.rank_deficient_ls(k, nd, nn)[0]
+    if kind == "ash219":
+        return ash219_standin()
+    if kind == "rand":
+        m, n, seed = (int(x) for x in arg.split("x"))
+        A = sp.random(m, n, density=3.0 / n, random_state=seed, format="csc")
+        A = A + sp.vstack([sp.identity(n), sp.csc_matrix((m - n, n))]) * 2.0
+        return sp.csc_matrix(A)
+    raise ValueError(name)
+
+
+def reference(A, ordering, tol=NO_TOL, want_R=True):
+    r = ref.spqr(A, ordering=ordering, tol=tol, symbolic=True, want_R=want_R)
+    if r.n1cols:
+        pytest.skip("the reference removed column singletons; the GPU path sees the pruned matrix")
+    r.Q = r.Q1fill if r.Q1fill.size else np.arange(A.shape[1], dtype=np.int64)
+    return r
+
+
+def check_symbolic(sym, r):
+    """Every symbolic array equal to the reference's QRsym, entry for entry."""
+    assert int(sym.nf) == r.nf, ("nf", sym.nf, r.nf)
+    nf = r.nf
+    for k in SYM_ARRAYS:
+        a, b = np.asarray(getattr(sym, k)), getattr(r, k)
+        if k == "Qfill" and b.size == 0:
+            b = np.arange(r.sn)
+        assert len(a) == len(b) and np.array_equal(a, b), k
+    for k in ("Fm", "Cm"):
+        assert np.array_equal(np.asarray(getattr(sym, k))[:nf], getattr(r, k)[:nf]), k
+    assert float(sym.flopcount) == r.flopcount_bound
+    # Sj: the reference's CPU build keeps global columns, the GPU path front-local ones
+    # (spqr_analyze.cpp:858-882); map ours back through Rj and compare
+    Sj = np.asarray(sym.Sj)
+    Sp, Sleft, Super, Rp, Rj = (np.asarray(getattr(sym, k)) for k in ("Sp", "Sleft", "Super", "Rp", "Rj"))
+    glob = np.empty_like(Sj)
+    for f in range(nf):
+        lo, hi = Sp[Sleft[Super[f]]], Sp[Sleft[Super[f + 1]]]
+        glob[lo:hi] = Rj[Rp[f] + Sj[lo:hi]]
+    lo = Sp[Sleft[Super[nf]]] if nf > 0 else 0
+    glob[lo:] = Sj[lo:]
+    assert np.array_equal(glob[:lo], r.Sj[:lo]), "Sj"
+
+
+def squeeze_order(Rdead, n):
+    """Live columns first, dead ones after: the column order of the R that [R,E] = qr(A) returns for a
+    rank-deficient A (SPQR/Source/spqr_rmap.cpp)."""
+    dead = np.asarray(Rdead[:n]).astype(bool)
+    return np.concatenate([np.nonzero(~dead)[0], np.nonzero(dead)[0]])
+
+
+def check_numeric(R, rank, Rdead, r, tol=1e-12):
+    """R (scipy sparse, rank-by-n, columns in the factorization's own order) against the reference's
+    [R,E] = qr(A): same rank, same dead columns, same E, |R| equal to tol of its largest entry
+    (rows of R are unique up to sign).  Returns the largest relative difference."""
+    n = r.n
+    assert int(rank) == r.rank == r.rank_R, (rank, r.rank, r.rank_R)
+    assert np.array_equal(np.asarray(Rdead[:n]).astype(np.int8), r.Rdead[:n])
+    order = squeeze_order(r.Rdead, n)
+    assert np.array_equal(r.Q[order], r.E)
+    Ra = abs(sp.csc_matrix(R))[:, order].tocsc()[:rank]
+    Rg = abs(sp.csc_matrix(r.R))[:rank]
+    scale = float(Rg.max())
+    diff = abs(Ra - Rg)
+    err = float(diff.max()) / scale if diff.nnz else 0.0
+    assert err <= tol, err
+    return err
