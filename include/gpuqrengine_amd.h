@@ -164,6 +164,14 @@ void gpuqr_replay_free (gpuqr_replay *rp);
  * (GPUQREngine/Source/TaskDescriptor/TaskDescriptor_flops.cpp:70-104). */
 int64_t gpuqr_front_flops (int64_t fm, int64_t fn, const int64_t *Stair);
 
+/* The per-task counts that sum is made of: the reference's formulas flopsFactorizeVT / flopsFactorize /
+ * flopsApply (TaskDescriptor_flops.cpp:18-28, :34-42, :48-53) evaluated at the task's own dimensions.
+ * On the reference's tile shapes (m = 32*numTiles rows, n = 32 columns, k = 32 reflectors) they are the
+ * reference's numbers.  They differ from a reference run's total because the tasks differ: a panel
+ * task here covers up to 256 rows (the reference's at most 96), so there are fewer merge levels. */
+int64_t gpuqr_flops_factorize (int64_t m, int64_t n, int with_t);
+int64_t gpuqr_flops_apply (int64_t m, int64_t k, int64_t n);
+
 /* Host allocator hooks, the analogue of SuiteSparse_config's function table
  * (SuiteSparse_config/SuiteSparse_config.h:87-91): every host allocation the
  * engine makes goes through these.  NULL restores malloc/calloc/free. */

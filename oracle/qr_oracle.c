@@ -475,3 +475,29 @@ void oracle_multifrontal_tol
     }
     if (norm_E_fro) *norm_E_fro = sqrt (wssq) ;
 }
+
+/* --------------------------------------------------------------------------
+ * the reference's per-task flop counts, restated from
+ * GPUQREngine/Source/TaskDescriptor/TaskDescriptor_flops.cpp:18-53 with its
+ * constant TILESIZE = 32 (GPUQREngine_Common.hpp:39)
+ * -------------------------------------------------------------------------- */
+
+Long oracle_flops_factorize_vt (int numTiles)
+{
+    Long m = 32 * (Long) numTiles, n = 32, v = 32 ;
+    return 2 * (m-1) + v * (6 + 4*m*n + 5*n + 2*m) + ((-4*n -2*m -5) * (v*(v+1)/2))
+        + 3 * (v*(v+1)*(2*v+1)/6) + (- 2*(m-v+1)*(n-v) - 2*(m-v-1)) ;
+}
+
+Long oracle_flops_factorize (int m_, int n_)
+{
+    Long m = m_, n = n_, v = (m < n) ? m : n ;
+    return 2 * (m-1) + v * (6 + 4*m*n + 5*n + 2*m) + ((-4*n -2*m -4) * v*(v+1)/2)
+        + 2 * v*(v+1)*(2*v+1)/6 + (- 2*(m-v+1)*(n-v) - 2*(m-v-1)) ;
+}
+
+Long oracle_flops_apply (int numTiles, int n_)
+{
+    Long m = 32 * (Long) numTiles, k = 32, n = n_ ;
+    return k*n*(4*m - k + 3) ;
+}

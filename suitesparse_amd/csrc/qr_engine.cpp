@@ -237,18 +237,21 @@ static inline int tier_of (int K)
     return (K <= 32) ? 0 : (K <= 64) ? 1 : (K <= 128) ? 2 : 3 ;
 }
 
+// The reference's own flop counts per task (GPUQREngine/Source/TaskDescriptor/TaskDescriptor_flops.cpp),
+// with its tile constants replaced by the task's dimensions: flopsFactorizeVT (:18-28) is the formula
+// for m = 32*numTiles rows, n = v = 32 columns, flopsFactorize (:34-42) the one without T for any m, n
+// with v = min(m, n), flopsApply (:48-53) k*n*(4m - k + 3) for k = 32 reflectors of m rows on n columns.
+// Here a panel task has K <= 256 rows (not <= 96) and w <= 32 columns, so the counts are the
+// reference's formulas at (K, w): equal to the reference's numbers on its own tile shapes.
 static int64_t flops_factorize (int64_t K, int64_t w, bool with_t)
 {
-    int64_t fl = 0 ;
-    int64_t kmax = (K < w) ? K : w ;
-    for (int64_t k = 0 ; k < kmax ; k++)
-    {
-        int64_t h = K - k ;                     // length of the reflector
-        fl += 2*(h-1) + 6 ;                     // sum of squares, sqrt, scaling
-        fl += 4*h*(w-k-1) ;                     // v'A and the rank-1 update
-        if (with_t) fl += 2*h*k + k*k ;         // v_j'v_k and the T column
-    }
-    return fl ;
+    const int64_t m = K, n = w, v = (m < n) ? m : n ;
+    if (m <= 0 || n <= 0) return 0 ;
+    if (with_t)
+        return 2 * (m-1) + v * (6 + 4*m*n + 5*n + 2*m) + ((-4*n - 2*m - 5) * (v*(v+1)/2))
+            + 3 * (v*(v+1)*(2*v+1)/6) + (- 2*(m-v+1)*(n-v) - 2*(m-v-1)) ;
+    return 2 * (m-1) + v * (6 + 4*m*n + 5*n + 2*m) + ((-4*n - 2*m - 4) * v*(v+1)/2)
+        + 2 * v*(v+1)*(2*v+1)/6 + (- 2*(m-v+1)*(n-v) - 2*(m-v-1)) ;
 }
 
 static inline int64_t flops_apply (int64_t K, int64_t w, int64_t n)
@@ -256,6 +259,9 @@ static inline int64_t flops_apply (int64_t K, int64_t w, int64_t n)
     // TaskDescriptor_flops.cpp:48-53 with m = K rows and k = w reflectors
     return w * n * (4*K - w + 3) ;
 }
+
+extern "C" int64_t gpuqr_flops_factorize (int64_t m, int64_t n, int with_t) { return flops_factorize (m, n, with_t != 0) ; }
+extern "C" int64_t gpuqr_flops_apply (int64_t m, int64_t k, int64_t n) { return flops_apply (m, k, n) ; }
 
 struct Seg { int32_t row, n ; } ;
 
@@ -1242,7 +1248,9 @@ cleanup:
 }
 
 // Fingerprint of everything the schedule and the task descriptors are built from: the front
-// descriptors as they stand (shapes, flags, every pointer) and the contents of the staircases.
+// descriptors as they stand (shapes, flags, every pointer), the contents of the staircases and of
+// the host row maps (the planner orders the row-block hand-over of a contribution block by the
+// values of cpuRimap, so two batches that differ only there need different schedules).
 // Two calls with the same fingerprint differ at most in the values stored behind the pointers.
 static uint64_t problem_fingerprint (const gpuqr_front *fronts, int64_t nf)
 {
@@ -1263,6 +1271,7 @@ static uint64_t problem_fingerprint (const gpuqr_front *fronts, int64_t nf)
     {
         mix (&fronts [f], sizeof (gpuqr_front)) ;
         if (fronts [f].Stair != NULL && fronts [f].fn > 0) mix (fronts [f].Stair, (size_t) fronts [f].fn * sizeof (int64_t)) ;
+        if (fronts [f].cpuRimap != NULL && fronts [f].cm > 0) mix (fronts [f].cpuRimap, (size_t) fronts [f].cm * sizeof (int32_t)) ;
     }
     return h | 1 ;
 }

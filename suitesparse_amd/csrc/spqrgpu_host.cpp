@@ -1249,12 +1249,19 @@ static int factorize_impl
                     const size_t bytes = (size_t) rsum * sizeof (double) ;
                     if (g + 1 < ngroups && !rp && getenv ("GPUQR_SERIAL_R") == NULL)
                     {
-                        r_thread_src = src ;
-                        r_thread = std::thread ([&WS, &r_thread_err, dst, src, bytes, wdev] ( )
+                        bool started = false ;
+                        try
                         {
-                            r_thread_err = hipSetDevice (wdev) ;
-                            if (r_thread_err == hipSuccess) r_thread_err = copy_to_pageable (dst, src, bytes, WS.hBounce) ;
-                        }) ;
+                            r_thread = std::thread ([&WS, &r_thread_err, dst, src, bytes, wdev] ( )
+                            {
+                                r_thread_err = hipSetDevice (wdev) ;
+                                if (r_thread_err == hipSuccess) r_thread_err = copy_to_pageable (dst, src, bytes, WS.hBounce) ;
+                            }) ;
+                            started = true ;
+                        }
+                        catch (...) { }         // no thread to be had: copy here and now
+                        if (started) r_thread_src = src ;
+                        else HIPCHK (copy_to_pageable (dst, src, bytes, WS.hBounce)) ;
                     }
                     else HIPCHK (copy_to_pageable (dst, src, bytes, WS.hBounce)) ;
                 }
@@ -1705,10 +1712,11 @@ extern "C" void spqr_amd_qt_free (spqr_amd_qt *qt)
     if (!qt) return ;
     int cur = -1 ;
     (void) hipGetDevice (&cur) ;
-    if (qt->device >= 0 && qt->device != cur) (void) hipSetDevice (qt->device) ;
+    const int dev = qt->device ;            // read before the object is gone
+    if (dev >= 0 && dev != cur) (void) hipSetDevice (dev) ;
     qt->~spqr_amd_qt ( ) ;
     host_free (qt) ;
-    if (cur >= 0 && qt->device != cur) (void) hipSetDevice (cur) ;
+    if (cur >= 0 && dev >= 0 && dev != cur) (void) hipSetDevice (cur) ;
 }
 
 extern "C" int spqrgpu_amd_factorize_keep
@@ -1884,6 +1892,8 @@ extern "C" int spqr_amd_rsolve
     const Long nf = S->nf, n = nacols, rank = num->sumfrank ;
     if (ldc < std::max ((Long) 1, rank)) return 3 ;
     for (Long f = 0 ; f < nf ; f++) if (num->Rblock [f] < 0) return 3 ;      // a part of R lives elsewhere
+    // X has nacols rows: the permutation may only send the first nacols columns there
+    if (Qfill) for (Long j = 0 ; j < n ; j++) if (Qfill [j] < 0 || Qfill [j] >= n) return 3 ;
     try
     {
         const Long maxfrank = std::max ((Long) 1, num->maxfrank) ;

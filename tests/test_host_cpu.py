@@ -191,6 +191,37 @@ def test_flopcount_formula():
     assert sym.flopcount == want
 
 
+def test_task_flop_counts_are_the_references_formulas():
+    """gpuqr_flops_factorize / gpuqr_flops_apply against the oracle's restatement of flopsFactorizeVT,
+    flopsFactorize and flopsApply (GPUQREngine/Source/TaskDescriptor/TaskDescriptor_flops.cpp:18-53) on
+    the reference's tile shapes, and gpuqr_front_flops as their sum over one front's tasks."""
+    L = _lib.lib()
+    O = oracle.lib()
+    for f in (L.gpuqr_flops_factorize, L.gpuqr_flops_apply, L.gpuqr_front_flops, O.oracle_flops_factorize_vt,
+              O.oracle_flops_factorize, O.oracle_flops_apply):
+        f.restype = C.c_int64
+    L.gpuqr_flops_factorize.argtypes = [C.c_int64, C.c_int64, C.c_int]
+    L.gpuqr_flops_apply.argtypes = [C.c_int64, C.c_int64, C.c_int64]
+    O.oracle_flops_factorize_vt.argtypes = [C.c_int]
+    O.oracle_flops_factorize.argtypes = [C.c_int, C.c_int]
+    O.oracle_flops_apply.argtypes = [C.c_int, C.c_int]
+    for tiles in (1, 2, 3):
+        assert L.gpuqr_flops_factorize(32 * tiles, 32, 1) == O.oracle_flops_factorize_vt(tiles)
+        for n in (32, 64, 2048, 16384):
+            assert L.gpuqr_flops_apply(32 * tiles, 32, n) == O.oracle_flops_apply(tiles, n)
+    for m, n in [(96, 32), (64, 32), (32, 32), (17, 9), (9, 17), (72, 64), (256, 32), (1, 1)]:
+        assert L.gpuqr_flops_factorize(m, n, 0) == O.oracle_flops_factorize(m, n)
+    # the paper's numbers for the reference's tasks (TaskDescriptor_flops.cpp evaluated by hand)
+    assert O.oracle_flops_factorize_vt(3) == 2 * 95 + 32 * (6 + 4 * 96 * 32 + 160 + 192) + (-128 - 192 - 5) * 528 + 3 * 11440 - 2 * 63
+    assert O.oracle_flops_apply(3, 64) == 32 * 64 * (4 * 96 - 29)
+    # one 256 x 32 front: a single panel task without T
+    L.gpuqr_front_flops.argtypes = [C.c_int64, C.c_int64, C.c_void_p]
+    assert L.gpuqr_front_flops(256, 32, None) == L.gpuqr_flops_factorize(256, 32, 0)
+    # 256 x 64: panel 0 with T (256 rows), its update of 32 columns, panel 1 on rows 32.. without T
+    assert L.gpuqr_front_flops(256, 64, None) == (L.gpuqr_flops_factorize(256, 32, 1) + L.gpuqr_flops_apply(256, 32, 32)
+                                                  + L.gpuqr_flops_factorize(224, 32, 0))
+
+
 # ---------------------------------------------------------------- C ABI surface
 
 def test_library_exports_every_declared_symbol():
