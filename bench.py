@@ -1,24 +1,35 @@
 #!/usr/bin/env python3
 """Benchmark of the numeric sparse QR hot path on MI355X.
 
-Headline workload: numeric multifrontal QR of the 3D 7-point grid least-squares matrix
-A = [L ; sqrt(0.1) I] on a 96^3 grid (m = 1,769,472, n = 884,736; BASELINE.json configs[3] is the
-same generator at 128^3, whose 45 s steps do not fit a run of 25 of them; it is carried as a one-call
-extra).  A step is one numeric factorization through the SPQR glue's C entry point (S built on the
+Headline workload = BASELINE.json configs[3]: numeric multifrontal QR of the 3D 7-point grid
+least-squares matrix A = [L ; sqrt(0.1) I] on a 128^3 grid (m = 4,194,304, n = 2,097,152), columns in
+the reference's METIS order, fronts as SPQR's analysis makes them (CHOLMOD's relaxed supernodes), no
+tolerance.  A step is one numeric factorization through the SPQR glue's C entry point (S built on the
 device from A's values, front assembly, panel factorization, block-reflector updates, R packed and
 copied to the host stack).  The metric is the reference's canonical flop count of the symbolic analysis
-(SPQR/Source/spqr_analyze.cpp:888-902) divided by wall time.
+(SPQR/Source/spqr_analyze.cpp:888-902, = cc->SPQR_flopcount) divided by wall time.
+
+The column order is an INPUT of the path (the reference computes it in spqr_1colamd before the
+numeric phase).  It comes from the reference's own METIS binding, run on the host through the
+reference build that also provides the CPU baseline (oracle/_ref); without that build the geometric
+nested-dissection order of suitesparse_amd.problems is used and the line says so.
 
 --gpus N > 1: the SAME problem on N ranks (strong scaling).  The assembly tree is mapped onto the
 ranks (suitesparse_amd/multigpu.py), every rank factorizes its fronts, contribution blocks cross ranks
-device to device over RCCL.
+device to device over RCCL.  Without a launcher (WORLD_SIZE unset) the N ranks are started here.
 
-The timed steps re-factorize on one symbolic object, as a solver inside an iteration does: pattern
-work and the engine's schedule are reused ("refactorization": true); the first call, which includes
-them, is reported beside it ("cold_first_call_ms").
+Which number is which: "value" = re-factorization on one symbolic object, as a solver inside an
+iteration does (pattern work and the engine's schedule reused, "refactorization": true);
+"value_first_factorization" = the first call on a fresh symbolic object, the region the reference
+times as SPQR_factorize_time (SPQR/Source/spqr_1factor.cpp:628-638: assembly maps, S, the numeric
+factorization; here also the device workspaces, which this fork allocates at symbolic time).
 
-Extras at N = 1 (same JSON line, key "extras"): 128^3 (the cold call and one re-factorization), the 2D 1024^2 grid
-(BASELINE.json configs[2]) and the dense front batch (configs[1]).
+"verified": after the timed steps and outside them, the R of the last one is checked the way the
+reference's test suite checks an R factor (check_r_factor, SPQR/Tcov/qrtest.cpp:1218-1257, bar 1e-10),
+through a random vector: max |R'(R y) - (AE)'((AE) y)| / max |(AE)'((AE) y)|.
+
+Extras at N = 1 (same JSON line, key "extras"): the 2D 1024^2 grid (configs[2]), the dense front batch
+(configs[1]) and the 96^3 grid of the earlier rounds' headline.
 """
 import argparse
 import json
@@ -39,7 +50,7 @@ PEAK_HBM_GBS = 8000.0
 KERNEL_NAMES = ["k_factorize<4, 8>", "k_factorize<4, 16>", "k_factorize<8, 16>", "k_factorize<16, 16>",
                 "k_apply<2>", "k_apply<4>", "k_apply<8>", "k_apply<16>", "k_assemble",
                 "k_factorize_all", "k_apply_small", "k_apply_all", "k_round_all"]
-HEADLINE = "sparse3d:96"
+HEADLINE = "sparse3d:128"
 # device memory declared to the staging (cc->gpuMemorySize); BENCH_DEVICE_GIB overrides it, e.g. when ranks of a
 # rehearsal share one device
 DECLARED_DEVICE_MEMORY = int(float(os.environ.get("BENCH_DEVICE_GIB", "200")) * 2**30)
@@ -69,34 +80,71 @@ def cpu_baseline_dense():
                       % (len(shapes), fl / 1e9, sec)}
 
 
+def reference_available():
+    try:
+        from oracle import ref
+        return ref.available()
+    except Exception:
+        return False
+
+
+def column_order(cx, A, shape, want):
+    """The column order the factorization is given: the reference's METIS order of A'A (rank 0 runs the
+    reference's binding on the host and hands the permutation to the other ranks), or the geometric
+    nested dissection when the reference build is absent or --ordering nd asks for it."""
+    import torch
+    import torch.distributed as dist
+    from suitesparse_amd import problems
+    n = A.shape[1]
+    use_ref = (want == "metis") and reference_available()
+    t0 = time.perf_counter()
+    if not use_ref:
+        return problems.nested_dissection(shape, leaf=8), "geometric nested dissection (suitesparse_amd.problems)", 0.0
+    if cx.rank == 0:
+        from oracle import ref
+        Q = np.ascontiguousarray(ref.metis_order(A), dtype=np.int64)
+    else:
+        Q = np.zeros(n, dtype=np.int64)
+    if cx.world > 1:
+        t = torch.from_numpy(Q).to(cx.dev if cx.backend == "nccl" else "cpu")
+        dist.broadcast(t, src=0)
+        Q = t.cpu().numpy()
+    return Q, "METIS on A'A through the reference's cholmod_l_metis (SPQR_ORDERING_METIS)", time.perf_counter() - t0
+
+
 def cpu_baseline_sparse(kind, k):
-    """The CPU multifrontal path of the oracle on a bounded sample of the same generator (the grid
-    shrunk until the run takes 10-30 s): fronts in postorder, each factorized by LAPACK's blocked
-    Householder QR (dgeqrf = dlarfg/dlarft/dlarfb, what SPQR's CPU path calls) on the host's threaded
-    BLAS, all cores; 2D grids (small fronts, nothing for a threaded BLAS to do) use the scalar C port."""
+    """The REFERENCE's own CPU path (SuiteSparseQR -> spqr_1factor -> spqr_front on MKL's threaded
+    LAPACK/BLAS, built from the reference's sources into oracle/_ref) timed on this host's cores, on a
+    bounded sample of the same generator and ordering: the reference's own SPQR_factorize_time and
+    flop count.  Without that build: the LAPACK-per-front port of the oracle."""
+    from suitesparse_amd import problems
+    ks = min(k, 1024 if kind == "sparse2d" else 40)
+    shape = (ks, ks) if kind == "sparse2d" else (ks, ks, ks)
+    A = problems.stacked_ls(shape)
+    if reference_available():
+        from oracle import ref
+        cores = ref.threads()
+        r = ref.spqr(A, ordering=ref.ORDERING_METIS, tol=ref.NO_TOL, symbolic=True, want_R=False)
+        return {"value": r.flopcount / r.factorize_time / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "reference",
+                "sample": "%s grid %s of the same generator, METIS order: the reference's SuiteSparseQR on the host "
+                          "(SPQR_factorize_time %.2f s, SPQR_analyze_time %.2f s, SPQR_flopcount %.2f GFLOP, %d fronts)"
+                          % (kind, "x".join(map(str, shape)), r.factorize_time, r.analyze_time, r.flopcount / 1e9, r.nf)}
     from oracle import oracle
-    from suitesparse_amd import problems, spqr
-    ks = min(k, 640 if kind == "sparse2d" else 40)
+    from suitesparse_amd import spqr
+    ks = min(ks, 640 if kind == "sparse2d" else 40)
     shape = (ks, ks) if kind == "sparse2d" else (ks, ks, ks)
     A = problems.stacked_ls(shape)
     sym = spqr.analyze(A, problems.nested_dissection(shape, leaf=8), relax=20, gpuMemorySize=DECLARED_DEVICE_MEMORY)
     Sx = spqr.s_values(sym, A)
-    if kind == "sparse2d":
-        t0 = time.perf_counter()
-        oracle.multifrontal(sym, Sx)
-        sec = time.perf_counter() - t0
-        cores, how = 1, "scalar C port"
-    else:
-        try:
-            from threadpoolctl import threadpool_info
-            cores = max([i.get("num_threads", 1) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
-        except ImportError:
-            cores = 1
-        _, t_qr, sec = oracle.multifrontal_lapack(sym, Sx, keep_R=False)
-        how = "LAPACK dgeqrf per front on threaded BLAS (%.1f s of it in dgeqrf)" % t_qr
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([i.get("num_threads", 1) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
+    except ImportError:
+        cores = 1
+    _, t_qr, sec = oracle.multifrontal_lapack(sym, Sx, keep_R=False)
     return {"value": sym.flopcount / sec / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
-            "sample": "%s grid %s of the same generator, %s (%.2f GFLOP, %.1f s)"
-                      % (kind, "x".join(map(str, shape)), how, sym.flopcount / 1e9, sec)}
+            "sample": "%s grid %s of the same generator, LAPACK dgeqrf per front on threaded BLAS (%.2f GFLOP, %.1f s)"
+                      % (kind, "x".join(map(str, shape)), sym.flopcount / 1e9, sec)}
 
 
 class Ctx:
@@ -124,12 +172,13 @@ def read_profile(L):
 
 def pmc_traffic(kernel, workload_tag):
     """HBM bytes per launch of `kernel` from the committed counter summary of this workload, or None."""
-    for fname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))
-            if pmc.get("workload_tag", "dense") == workload_tag and kernel in pmc["kernels"]:
-                return (pmc["kernels"][kernel]["traffic_bytes_per_launch"],
-                        "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)" % fname)
+            for entry in (pmc if isinstance(pmc, list) else [pmc]):
+                if entry.get("workload_tag", "dense") == workload_tag and kernel in entry["kernels"]:
+                    return (entry["kernels"][kernel]["traffic_bytes_per_launch"],
+                            "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)" % fname)
         except (OSError, ValueError, KeyError):
             pass
     return None, None
@@ -138,6 +187,7 @@ def pmc_traffic(kernel, workload_tag):
 def rooflines(per_kernel, best, workload_tag):
     """`roofline` of the kernel with the largest total time, `roofline_assembly` of k_assemble."""
     roofline = roofline_assembly = None
+    total_ms = sum(v["ms"] for v in per_kernel.values()) or 1.0
     if best is not None:
         name, ms, ln, fl, by = best
         # HBM bytes per launch from the hardware counters: collected with rocprofv3 --pmc in separate
@@ -146,17 +196,19 @@ def rooflines(per_kernel, best, workload_tag):
         avg_s = ms / 1e3 / ln
         tflops = fl / ln / avg_s / 1e12
         gbs = by / ln / avg_s / 1e9
-        # the 32-column block reflector does about 8 flop per byte of A it must move, below the
-        # chip's FP64 ridge (78.6 TF / 8 TB/s = 9.8): HBM bounds it
-        if name.startswith("k_apply") or name.startswith("k_assemble"):
-            roofline = {"kernel": name, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                        "avg_launch_us": avg_s * 1e6, "launches": ln, "algorithmic_bytes_per_launch": by / ln,
-                        "mfma_tflops": tflops, "mfma_frac": tflops / PEAK_FP64_MFMA_TFLOPS}
-        else:
-            roofline = {"kernel": name, "bound": "mfma", "achieved": tflops, "peak": PEAK_FP64_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
-                        "avg_launch_us": avg_s * 1e6, "launches": ln}
+        # The block-reflector update moves 16 bytes per entry of the trailing matrix for about 4 w flops
+        # (w reflectors): 8 flop/B at w = 32, 16 at w = 64, against the chip's FP64 ridge of 78.6 TF / 8 TB/s
+        # = 9.8.  The panel kernels issue no MFMA and are bound by latency; they are priced against the
+        # memory roof too (their bytes are what they must move) and their share of the time is what counts.
+        roofline = {"kernel": name, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                    "avg_launch_us": avg_s * 1e6, "launches": ln, "algorithmic_bytes_per_launch": by / ln,
+                    "time_share": ms / total_ms}
+        if name.startswith("k_apply") or name.startswith("k_round"):
+            roofline.update({"mfma_tflops": tflops, "mfma_frac": tflops / PEAK_FP64_MFMA_TFLOPS,
+                             "flop_per_byte": fl / max(by, 1.0)})
+        elif name.startswith("k_factorize"):
+            roofline["note"] = "panel kernel: latency-bound (one barrier per column), no MFMA; see time_share"
     if "k_assemble" in per_kernel and per_kernel["k_assemble"]["ms"] > 0:
         ka = per_kernel["k_assemble"]
         gbs_a = ka["gbytes"] / (ka["ms"] / 1e3)
@@ -165,10 +217,10 @@ def rooflines(per_kernel, best, workload_tag):
                              "unit": "GB/s", "frac": gbs_a / PEAK_HBM_GBS, "traffic": traffic_a,
                              "avg_launch_us": ka["ms"] * 1e3 / ka["launches"], "launches": ka["launches"],
                              "algorithmic_bytes_per_launch": ka["gbytes"] * 1e9 / ka["launches"],
-                             "note": "many small launches beside the updates (contribution blocks travel 32 rows at a "
-                                     "time); their sum is 3 % of the kernel time at 96^3, where whole-front "
-                                     "hand-over (GPUQR_NO_PIPELINE=1) moves the same bytes in 353 launches at "
-                                     "2.28 TB/s and makes the step 12 % longer"}
+                             "time_share": ka["ms"] / total_ms,
+                             "note": "launches beside the updates (contribution blocks travel 32 rows at a time); "
+                                     "the kernel alone on large blocks: scripts/ubench/assemble_bench.hip, "
+                                     "profiles/r03_ubench_assemble.txt"}
     return roofline, roofline_assembly
 
 
@@ -196,7 +248,7 @@ def time_steps(cx, step, prepare, K, W, nbuf=1):
         if i >= nbuf:
             prepare(W + i)          # not enough memory for one buffer per step: restore inside the timed region
         st = ss.QREngineStats()
-        step(W + i, st)
+        step(W + i, st, last=(i == K - 1))
         kernel_ms += st.kernelTime
         launches = st.numLaunches
     barrier()
@@ -248,33 +300,50 @@ def run_dense(cx, K, W, copies=COPIES):
     def prepare(i):
         bufs[i % nbuf].copy_(src)
 
-    def step(i, stats=None):
+    def step(i, stats=None, last=False):
         code = ss.GPUQREngine(0, front_sets[i % nbuf], len(shapes), stats=stats)
         assert code == ss.QRENGINE_SUCCESS, code
 
     elapsed, kernel_ms, launches = time_steps(cx, step, prepare, K, W, nbuf)
+    # the check of the reference's dense demo (||triu(R)'triu(R) - A'A||_1 / ||A'A||_1 <= 1e-12,
+    # GPUQREngine/Demo/gpuqrengine_demo.cpp:94-100) on the largest front of every width, from the last step
+    lastbuf = bufs[(W + K - 1) % nbuf]
+    worst, off = 0.0, 0
+    for (m, n) in shapes:
+        if m == FM[-1]:
+            Fr = lastbuf[off:off + m * n].view(m, n)
+            Ar = src[off:off + m * n].view(m, n)
+            R = torch.triu(Fr[:min(m, n)])
+            G = Ar.T @ Ar
+            worst = max(worst, float((R.T @ R - G).abs().sum(0).max() / G.abs().sum(0).max()))
+        off += m * n
+    verified = {"check": "||triu(R)'triu(R) - A'A||_1 / ||A'A||_1 on every 4096-row front of the last step "
+                         "(gpuqrengine_demo.cpp:94-100, bar 1e-12)", "value": worst, "passed": worst <= 1e-12}
     per_kernel, best = profile_step(cx, step, prepare)
     workload = "dense-front-batch %dx{%s}x{%s}" % (copies, ",".join(map(str, FM)), ",".join(map(str, FN)))
     return dict(workload=workload, tag="dense", flops=flops, elapsed=elapsed, kernel_ms=kernel_ms, launches=launches,
-                per_kernel=per_kernel, best=best, scaling="weak",
+                per_kernel=per_kernel, best=best, scaling="weak", verified=verified,
                 config={"fronts": len(shapes), "bytes": total * 8})
 
 
-def run_sparse(cx, kind, k, K, W, single_call=False, profile=True):
-    """Time the sparse numeric factorization; single_call: one call in all, the cold one; profile=False
-    leaves out the extra step with events around every launch."""
+def run_sparse(cx, kind, k, K, W, ordering="metis", profile=True):
+    """Time the sparse numeric factorization: the cold first call (it is also the first warm-up), W-1
+    more warm-ups, K timed steps, the check of the last R, one profiled step."""
     import torch
     from suitesparse_amd import multigpu, problems, spqr
     t0 = time.perf_counter()
     shape = (k, k) if kind == "sparse2d" else (k, k, k)
     A = problems.stacked_ls(shape)
-    Q = problems.nested_dissection(shape, leaf=8)
-    sym = spqr.analyze(A, Q, relax=20, gpuMemorySize=DECLARED_DEVICE_MEMORY)
-    analysis_s = time.perf_counter() - t0
-    workload = "%s grid %s stacked LS, geometric ND order, m=%d n=%d nf=%d" % (
-        kind, "x".join(map(str, shape)), A.shape[0], A.shape[1], sym.nf)
-    config = {"fronts": sym.nf, "stages": sym.numStages, "nnzR": sym.rnz, "m": A.shape[0], "n": A.shape[1],
-              "canonical_gflop": sym.flopcount / 1e9}
+    Q, order_name, order_s = column_order(cx, A, shape, ordering)
+    t1 = time.perf_counter()
+    # relax = -1: the fronts SPQR's own analysis makes for this column order (bit-identical arrays)
+    sym = spqr.analyze(A, Q, relax=-1, gpuMemorySize=DECLARED_DEVICE_MEMORY)
+    analysis_s = time.perf_counter() - t1
+    workload = "%s grid %s stacked LS (lambda 0.1), no tolerance, m=%d n=%d" % (kind, "x".join(map(str, shape)), A.shape[0], A.shape[1])
+    config = {"ordering": order_name, "analysis": "SPQR-compatible (CHOLMOD relaxed supernodes, spqr_amd_analyze relax=-1)",
+              "fronts": sym.nf, "stages": sym.numStages, "nnzR": sym.rnz, "m": A.shape[0], "n": A.shape[1],
+              "canonical_gflop": sym.flopcount / 1e9, "declared_device_GiB": DECLARED_DEVICE_MEMORY / 2**30,
+              "largest_front": [int(sym.Fm.max()), int(sym.maxfn)]}
     mapping = {}
     for parts in sorted({2, 4, 8, cx.world} - {1}):
         owner, level = multigpu.map_tree(sym, parts)
@@ -282,12 +351,12 @@ def run_sparse(cx, kind, k, K, W, single_call=False, profile=True):
         mapping[str(parts)] = {"top_flops_share": round(rep["top_flops_share"], 4),
                                "speedup_bound": round(rep["speedup_bound"], 3)}
     csc = multigpu._Csc(A)
-    last_info = {}
+    last_info, kept = {}, {}
 
     def prepare(i):
         pass
 
-    def step(i, stats=None):
+    def step(i, stats=None, last=False):
         if cx.world > 1:
             _, info = multigpu.factorize_distributed(sym, csc, gather_R=False)
             last_info.update(info)
@@ -295,26 +364,41 @@ def run_sparse(cx, kind, k, K, W, single_call=False, profile=True):
                 stats.kernelTime = sum(c["kernel_ms"] for c in info["calls"])
                 stats.numLaunches = sum(c["launches"] for c in info["calls"])
             return
-        res = spqr.factorize(sym, csc, want_R=False)      # R stays as packed blocks; CSC conversion is not on the path
+        # R stays as packed blocks on the host stack; the CSC conversion is not on the path.  The last
+        # timed step keeps its numeric object for the check that follows the timed region.
+        res = spqr.factorize(sym, csc, want_R=False, keep_num=last)
+        if last:
+            kept["res"] = res
         if stats is not None:
             stats.kernelTime, stats.numLaunches, stats.flopsActual = (
                 res.gpuKernelTime, res.gpuNumKernelLaunches, res.gpuFlops)
 
     # the first call: pattern work (maps, S permutation), workspace allocation, planning and upload
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    t0c = time.perf_counter()
     step(0)
     torch.cuda.synchronize()
-    cold_ms = (time.perf_counter() - t0) * 1e3
-    if single_call:
-        return dict(workload=workload, tag=kind, flops=sym.flopcount, elapsed=cold_ms / 1e3, kernel_ms=0.0, launches=0,
-                    per_kernel={}, best=None, scaling="strong", config=config, cold_ms=cold_ms,
-                    analysis_s=analysis_s, mapping=mapping, steps=1)
+    cold_ms = (time.perf_counter() - t0c) * 1e3
     elapsed, kernel_ms, launches = time_steps(cx, step, prepare, K, max(W - 1, 0))
+    verified = None
+    if "res" in kept:
+        tv = time.perf_counter()
+        res = kept.pop("res")
+        err = spqr.gram_probe(sym, res, A, seed=1)
+        verified = {"check": "max|R'(R y) - (AE)'((AE) y)| / max|(AE)'((AE) y)|, y random: check_r_factor "
+                             "(SPQR/Tcov/qrtest.cpp:1218-1257, bar 1e-10) through a vector, on the R of the last timed step",
+                    "value": err, "passed": bool(err <= 1e-10 and res.rank == sym.n), "rank": res.rank, "n": int(sym.n),
+                    "seconds": None}
+        res.free()
+        verified["seconds"] = round(time.perf_counter() - tv, 2)
+    elif cx.world > 1:
+        verified = {"check": "not run: R is spread over the ranks (tests/test_multigpu_cpu.py and the -m gpu rank tests "
+                             "compare the distributed R with the single-process one bit for bit)", "value": None, "passed": None}
     per_kernel, best = profile_step(cx, step, prepare) if profile else ({}, None)
     out = dict(workload=workload, tag="%s:%d" % (kind, k), flops=sym.flopcount, elapsed=elapsed, kernel_ms=kernel_ms,
                launches=launches, per_kernel=per_kernel, best=best, scaling="strong", config=config,
-               cold_ms=cold_ms, analysis_s=analysis_s, mapping=mapping)
+               cold_ms=cold_ms, analysis_s=analysis_s, ordering_s=order_s, mapping=mapping, verified=verified,
+               setup_s=time.perf_counter() - t0)
     if cx.world > 1:
         out["multi"] = {"levels": last_info.get("levels"), "cut_blocks": last_info.get("n_cut"),
                         "cut_bytes": last_info.get("cut_bytes"),
@@ -322,16 +406,42 @@ def run_sparse(cx, kind, k, K, W, single_call=False, profile=True):
     return out
 
 
+def spawn_ranks(n):
+    """bench.py --gpus N without a launcher: start the N ranks through torch.distributed.run, before this
+    process has touched a GPU, and relay rank 0's line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line)
+    else:
+        sys.stdout.write(proc.stdout)
+    return proc.returncode if line is None or proc.returncode != 0 else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=HEADLINE, help="sparse3d:K | sparse2d:K | dense")
+    ap.add_argument("--ordering", default="metis", choices=["metis", "nd"])
     ap.add_argument("--copies", type=int, default=COPIES)
     ap.add_argument("--extras", default="auto", choices=["auto", "none", "all"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -358,11 +468,11 @@ def main():
     cx.L = _lib.lib()
     K, W = args.steps, args.warmup
 
-    def run(workload, K, W, single_call=False, profile=True):
+    def run(workload, K, W, profile=True):
         if workload == "dense":
             return run_dense(cx, K, W, args.copies)
         kind, k = workload.split(":")
-        return run_sparse(cx, kind, int(k), K, W, single_call, profile)
+        return run_sparse(cx, kind, int(k), K, W, args.ordering, profile)
 
     res = run(args.workload, K, W)
 
@@ -377,14 +487,16 @@ def main():
             "data": "synthetic", "config": dict({"workload": res["workload"]}, **res["config"]),
             "kernel_ms_per_step": res["kernel_ms"], "launches_per_step": res["launches"],
             "pct_fp64_mfma_peak": 100.0 * value / cx.world / 1e3 / PEAK_FP64_MFMA_TFLOPS,
-            "roofline": roofline, "per_kernel": res["per_kernel"],
+            "roofline": roofline, "per_kernel": res["per_kernel"], "verified": res.get("verified"),
         }
         if roofline_assembly is not None:
             out["roofline_assembly"] = roofline_assembly
         if "cold_ms" in res:
             out["refactorization"] = True
             out["cold_first_call_ms"] = res["cold_ms"]
+            out["value_first_factorization"] = res["flops"] / (res["cold_ms"] / 1e3) / 1e9
             out["analysis_s"] = res["analysis_s"]
+            out["ordering_s"] = res["ordering_s"]
             out["mapping_bounds"] = res["mapping"]
             if cx.world > 1:
                 me = res["mapping"].get(str(cx.world), {})
@@ -396,9 +508,8 @@ def main():
         # ---- the other configurations, one short run each (N = 1 only) -----------------------------
         if cx.world == 1 and args.extras != "none" and args.workload == HEADLINE:
             extras = {}
-            # (config 4 at full size: the cold call, then one timed re-factorization; no profiled step, it is 33 s a call)
-            plan = [("sparse3d:128", 1, 1, False, 300.0), ("sparse2d:1024", 5, 2, False, 420.0), ("dense", 5, 2, False, 450.0)]
-            for wl, k_, w_, single, latest_start in plan:
+            plan = [("sparse2d:1024", 5, 2, 330.0), ("dense", 5, 2, 360.0), ("sparse3d:96", 1, 1, 300.0)]
+            for wl, k_, w_, latest_start in plan:
                 spent = time.perf_counter() - T_START
                 if args.extras == "auto" and spent > latest_start:
                     extras[wl] = {"skipped": "bench already %.0f s old" % spent}
@@ -406,22 +517,22 @@ def main():
                 try:
                     cx.L.spqrgpu_amd_finalize()      # give the previous problem's device workspaces back
                     torch.cuda.empty_cache()
-                    r = run(wl, k_, w_, single, profile=(wl != "sparse3d:128"))
-                    steps = r.get("steps", k_)
-                    v = r["flops"] * steps / r["elapsed"] / 1e9
-                    e = {"workload": r["workload"], "value": v, "unit": "GFLOP/s", "steps": steps,
-                         "ms_per_step": r["elapsed"] / steps * 1e3,
-                         "pct_fp64_mfma_peak": 100.0 * v / 1e3 / PEAK_FP64_MFMA_TFLOPS}
-                    if single:
-                        e["note"] = "one call, the cold one (pattern work, allocation and planning included)"
-                    else:
-                        rl, rla = rooflines(r["per_kernel"], r["best"], r["tag"])
-                        if rl is not None:
-                            e["roofline"] = rl
-                        if rla is not None:
-                            e["roofline_assembly"] = rla
-                        if "cold_ms" in r:
-                            e["cold_first_call_ms"] = r["cold_ms"]
+                    r = run(wl, k_, w_)
+                    v = r["flops"] * k_ / r["elapsed"] / 1e9
+                    e = {"workload": r["workload"], "config": r["config"], "value": v, "unit": "GFLOP/s", "steps": k_,
+                         "ms_per_step": r["elapsed"] / k_ * 1e3, "kernel_ms_per_step": r["kernel_ms"],
+                         "launches_per_step": r["launches"],
+                         "pct_fp64_mfma_peak": 100.0 * v / 1e3 / PEAK_FP64_MFMA_TFLOPS, "verified": r.get("verified")}
+                    rl, rla = rooflines(r["per_kernel"], r["best"], r["tag"])
+                    if rl is not None:
+                        e["roofline"] = rl
+                    if rla is not None:
+                        e["roofline_assembly"] = rla
+                    if "cold_ms" in r:
+                        e["cold_first_call_ms"] = r["cold_ms"]
+                        e["value_first_factorization"] = r["flops"] / (r["cold_ms"] / 1e3) / 1e9
+                    if wl == "sparse2d:1024" and not args.no_cpu_baseline:
+                        e["cpu_baseline"] = cpu_baseline_sparse("sparse2d", 1024)
                     extras[wl] = e
                 except Exception as ex:          # an extra must never take the headline down with it
                     extras[wl] = {"error": "%s: %s" % (type(ex).__name__, ex)}
@@ -433,6 +544,7 @@ def main():
             else:
                 kind, k = args.workload.split(":")
                 out["cpu_baseline"] = cpu_baseline_sparse(kind, int(k))
+        out["bench_seconds"] = round(time.perf_counter() - T_START, 1)
         print(json.dumps(out))
     if cx.world > 1:
         dist.barrier()                  # rank 0 is still printing while the others arrive here

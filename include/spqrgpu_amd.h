@@ -194,6 +194,15 @@ int spqrgpu_amd_qtmult (spqr_amd_qt *qt, const double *B, int64_t ldb, double *C
 int spqr_amd_rsolve (const spqr_amd_symbolic *sym, const spqr_amd_numeric *num, const int64_t *Qfill,
                      int64_t nacols, int64_t nrhs, const double *C, int64_t ldc, double *X);
 
+/* out = R in (transposed == 0: in has n entries in the factorization's column order, out rank entries) or
+ * out = R' in (transposed != 0: in rank entries, out n entries), on the packed R blocks of num, on the
+ * host.  No counterpart in the reference's library; its test suite forms R'R - (AP)'(AP) explicitly
+ * (check_r_factor, SPQR/Tcov/qrtest.cpp:1218-1257), these two products make the same comparison
+ * through a vector at sizes where that product cannot be formed.  Returns 0, 1 out of memory,
+ * 3 invalid argument (including a numeric object that holds only a part of R). */
+int spqr_amd_rmult (const spqr_amd_symbolic *sym, const spqr_amd_numeric *num, int transposed,
+                    const double *in, double *out);
+
 /* min || A x - B ||_2 from a kept factorization: spqrgpu_amd_qtmult on the device, then spqr_amd_rsolve
  * with the symbolic object's Qfill: what SuiteSparseQR_qmult (SPQR_QTX) followed by SuiteSparseQR_solve
  * (SPQR_RETX_EQUALS_B) do on the reference's factorization object, on the CPU

@@ -1,8 +1,8 @@
 """ctypes loader of oracle/_ref/libspqr_ref.so: the REFERENCE's own CPU SuiteSparseQR, compiled by
 oracle/build_ref.sh from the sources under /root/reference (unchanged, where they lie).
 
-TEST INFRASTRUCTURE ONLY: imported by tests/, tests/golden/make_golden.py and bench.py's cpu_baseline
-leg, never by the product.  The library travels to the GPU box as a built file (it is git-ignored,
+TEST INFRASTRUCTURE ONLY: imported by tests/ and bench.py's reference leg (column order and CPU
+baseline), never by the product.  The library travels to the GPU box as a built file (it is git-ignored,
 not gpurun-ignored); the reference tree does not, and nothing here reads it at run time."""
 import ctypes as C
 import os
@@ -109,6 +109,13 @@ def spqr(A, ordering=ORDERING_FIXED, tol=NO_TOL, symbolic=True, want_R=True):
         return r
     finally:
         L.ref_close(h)
+
+
+def threads():
+    """The number of threads MKL gives the reference's BLAS/LAPACK calls in this process."""
+    L = lib()
+    L.ref_threads.restype = C.c_int
+    return int(L.ref_threads())
 
 
 def metis_order(A):

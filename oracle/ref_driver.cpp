@@ -198,6 +198,10 @@ Long ref_stack_copy (void *hv, Long from, Long count, double *out)
     return (count) ;
 }
 
+// threads MKL will use for the BLAS/LAPACK calls of spqr_front (what "cores" means for the CPU baseline)
+extern "C" int MKL_Get_Max_Threads (void) ;
+int ref_threads (void) { return (MKL_Get_Max_Threads ( )) ; }
+
 // A'A ordering by the reference's METIS binding alone (what spqr_1colamd.cpp:561-608 calls for
 // ordering 6 when there are no singletons): cholmod_l_metis on A' with postorder, as CHOLMOD's
 // analyze does it.  Returns 0 on success.

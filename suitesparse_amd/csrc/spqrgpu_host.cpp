@@ -1960,6 +1960,96 @@ extern "C" int spqr_amd_rsolve
     return 0 ;
 }
 
+// t = R y (transposed == 0; y of size n in the factorization's column order, t of size rank) or
+// z = R' t (transposed != 0; z of size n), on the packed R blocks of num, on a few host threads.
+// The two products are what check_r_factor needs of R (SPQR/Tcov/qrtest.cpp:1218-1257 forms
+// R'R - (AP)'(AP) explicitly; R' (R y) against (AP)' ((AP) y) is the same test through a vector, at
+// sizes where the explicit product cannot be formed).  Fronts own disjoint rows of R, so R y needs no
+// synchronisation; for R' t every thread sums into a vector of its own.
+extern "C" int spqr_amd_rmult
+(
+    const spqr_amd_symbolic *S, const spqr_amd_numeric *num, int transposed, const double *in, double *out
+)
+{
+    if (!S || !num || !num->Rstack || !num->Rblock || !num->Rdead || !in || !out) return 3 ;
+    const Long nf = S->nf, n = S->n, rank = num->sumfrank ;
+    for (Long f = 0 ; f < nf ; f++) if (num->Rblock [f] < 0) return 3 ;
+    try
+    {
+        // first row of every front, block sizes for the split
+        hostvec<Long> row1 ((size_t) nf + 1), work ((size_t) nf + 1) ;
+        const char *Rdead = num->Rdead ;
+        Long r = 0, w = 0 ;
+        for (Long f = 0 ; f < nf ; f++)
+        {
+            row1 [f] = r ; work [f] = w ;
+            const Long col1 = S->Super [f], fp = S->Super [f+1] - col1, fn = S->Rp [f+1] - S->Rp [f] ;
+            Long rm = 0 ;
+            for (Long k = 0 ; k < fp ; k++) if (!Rdead [col1 + k]) rm++ ;
+            r += rm ; w += rm * fn + 1 ;
+        }
+        row1 [nf] = r ; work [nf] = w ;
+        if (r != rank) return 3 ;
+        unsigned hw = std::thread::hardware_concurrency ( ) ;
+        const char *env = getenv ("OMP_NUM_THREADS") ;
+        if (env && atoi (env) > 0) hw = (unsigned) atoi (env) ;
+        const unsigned nt = (unsigned) std::max<Long> (1, std::min<Long> ((Long) std::min (hw, 32u), w / 2000000 + 1)) ;
+        hostvec<double> zs ;
+        if (transposed && nt > 1) zs.assign ((size_t) n * (nt - 1), 0.0) ;
+        if (transposed) for (Long j = 0 ; j < n ; j++) out [j] = 0 ;
+        else for (Long i = 0 ; i < rank ; i++) out [i] = 0 ;
+        auto body = [&] (unsigned t)
+        {
+            const Long wlo = w * t / nt, whi = w * (t + 1) / nt ;
+            double *z = (!transposed || t == 0) ? out : zs.data ( ) + (size_t) n * (t - 1) ;
+            for (Long f = 0 ; f < nf ; f++)
+            {
+                if (work [f] < wlo || work [f] >= whi) continue ;
+                const double *R = num->Rstack + num->Rblock [f] ;
+                const Long col1 = S->Super [f], fp = S->Super [f+1] - col1 ;
+                const Long pr = S->Rp [f], fn = S->Rp [f+1] - pr, r1 = row1 [f] ;
+                Long rm = 0 ;
+                for (Long k = 0 ; k < fn ; k++)
+                {
+                    if (k < fp && !Rdead [col1 + k]) rm++ ;
+                    const Long j = S->Rj [pr + k] ;
+                    if (transposed)
+                    {
+                        double sum = 0 ;
+                        for (Long i = 0 ; i < rm ; i++) sum += R [i] * in [r1 + i] ;
+                        z [j] += sum ;
+                    }
+                    else
+                    {
+                        const double yj = in [j] ;
+                        if (yj != 0) for (Long i = 0 ; i < rm ; i++) z [r1 + i] += R [i] * yj ;
+                    }
+                    R += rm ;
+                }
+            }
+        } ;
+        if (nt == 1) body (0) ;
+        else
+        {
+            std::vector<std::thread> th ;
+            unsigned started = 0 ;
+            try { for (unsigned t = 1 ; t < nt ; t++) { th.emplace_back (body, t) ; started = t ; } }
+            catch (...) { }
+            body (0) ;
+            for (auto &x : th) x.join ( ) ;
+            for (unsigned t = started + 1 ; t < nt ; t++) body (t) ;     // threads that could not be had
+            if (transposed)
+                for (unsigned t = 1 ; t < nt ; t++)
+                {
+                    const double *z = zs.data ( ) + (size_t) n * (t - 1) ;
+                    for (Long j = 0 ; j < n ; j++) out [j] += z [j] ;
+                }
+        }
+    }
+    catch (std::bad_alloc &) { return 1 ; }
+    return 0 ;
+}
+
 // min || A x - B ||_2 from a kept factorization: X = E (R \ (Q'B)), Q'B on the device
 // (spqrgpu_amd_qtmult), the back substitution on the host (spqr_amd_rsolve).  What
 // SuiteSparseQR_solve (SPQR_RETX_EQUALS_B) composed with SuiteSparseQR_qmult (SPQR_QTX) gives on a

@@ -204,6 +204,38 @@ def rsolve(sym, res, Cq, nacols=None, permute=True):
     return X[:n, :k].copy()
 
 
+def rmult(sym, res, v, transposed=False):
+    """spqr_amd_rmult: R v (v of size n, the factorization's column order) or R' v (v of size rank) on the
+    packed R blocks of a factorization made with keep_num."""
+    L = _bind()
+    L.spqr_amd_rmult.restype = C.c_int
+    L.spqr_amd_rmult.argtypes = [C.c_void_p, C.POINTER(Numeric), C.c_int, C.c_void_p, C.c_void_p]
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    n, rank = int(sym.n), int(res.rank)
+    assert v.size == (rank if transposed else n)
+    out = np.zeros(max(n if transposed else rank, 1))
+    code = L.spqr_amd_rmult(sym._h, res._num, int(bool(transposed)), _p(v), _p(out))
+    if code != 0:
+        raise RuntimeError("spqr_amd_rmult failed with code %d" % code)
+    return out[:n if transposed else rank]
+
+
+def gram_probe(sym, res, A, seed=0):
+    """The reference's check of an R factor, ||R'R - (AP)'(AP)||_1 / ||A'A||_1 <= 1e-10
+    (check_r_factor, SPQR/Tcov/qrtest.cpp:1218-1257,2750), through one random vector: returns
+    max |R'(R y) - (AP)'((AP) y)| / max |(AP)'((AP) y)| for y uniform in (0.5, 1.5), P = Qfill.  For a
+    factorization of full column rank made with keep_num."""
+    A = sp.csc_matrix(A)
+    n = int(sym.n)
+    y = np.random.default_rng(seed).uniform(0.5, 1.5, size=n)
+    z = rmult(sym, res, rmult(sym, res, y), transposed=True)
+    yq = np.zeros(A.shape[1])
+    yq[np.asarray(sym.Qfill)[:n]] = y           # (A P) y = A (P y)
+    w = A.T @ (A @ yq)
+    z2 = w[np.asarray(sym.Qfill)[:n]]
+    return float(np.abs(z - z2).max() / np.abs(z2).max())
+
+
 def spqrgpu_computeFrontStaging(nf, Parent, Childp, Child, Fm, Cm, Rp, Sp, Sleft, Super, Post,
                                 RimapSize, RjmapSize, gpuMemorySize):
     """spqrgpu_computeFrontStaging (SPQR/Include/spqrgpu.hpp:16-57) on caller arrays.

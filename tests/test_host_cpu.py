@@ -418,6 +418,12 @@ def test_rsolve_on_packed_blocks_without_a_gpu():
     assert np.abs(x - xl).max() <= 1e-11 * np.abs(xl).max()
     y = spqr.rsolve(sym, Res, Cq, permute=False)
     assert np.array_equal(y, x[sym.Qfill])
+    # R v and R' v on the same blocks, and the vector form of check_r_factor built from them
+    Res.rank = n
+    v = rng.standard_normal(n)
+    assert np.abs(spqr.rmult(sym, Res, v) - R @ v).max() <= 1e-13 * np.abs(R @ v).max()
+    assert np.abs(spqr.rmult(sym, Res, v, transposed=True) - R.T @ v).max() <= 1e-13 * np.abs(R.T @ v).max()
+    assert spqr.gram_probe(sym, Res, A) <= 1e-13
     # a numeric object that holds only a part of R is refused
     Rblock[nf // 2] = -1
     with pytest.raises(RuntimeError):
