@@ -102,7 +102,7 @@ def column_order(cx, A, shape, want):
         return problems.nested_dissection(shape, leaf=8), "geometric nested dissection (suitesparse_amd.problems)", 0.0
     if cx.rank == 0:
         from oracle import ref
-        Q = np.ascontiguousarray(ref.metis_order(A), dtype=np.int64)
+        Q = np.ascontiguousarray(ref.metis_order_child(A), dtype=np.int64)      # (a child process: METIS takes and frees GBs of heap)
     else:
         Q = np.zeros(n, dtype=np.int64)
     if cx.world > 1:

@@ -127,3 +127,27 @@ def metis_order(A):
     if lib().ref_metis_order(m, n, _p(Ap), _p(Ai), _p(perm)) != 0:
         raise RuntimeError("cholmod_l_metis failed")
     return perm
+
+
+def metis_order_child(A):
+    """metis_order in a child process: METIS on a multi-million-column graph takes and frees several
+    GB of heap, which is kept out of a process that drives a GPU this way."""
+    import subprocess
+    import sys
+    import tempfile
+    A, Ap, Ai, _ = _csc(A)
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "Ap.npy"), Ap)
+        np.save(os.path.join(d, "Ai.npy"), Ai)
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), d, str(A.shape[0]), str(A.shape[1])])
+        return np.load(os.path.join(d, "perm.npy"))
+
+
+if __name__ == "__main__":
+    import sys
+    d, m, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    Ap, Ai = np.load(os.path.join(d, "Ap.npy")), np.load(os.path.join(d, "Ai.npy"))
+    perm = np.zeros(n, np.int64)
+    if lib().ref_metis_order(m, n, _p(Ap), _p(Ai), _p(perm)) != 0:
+        raise SystemExit("cholmod_l_metis failed")
+    np.save(os.path.join(d, "perm.npy"), perm)

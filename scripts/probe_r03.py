@@ -21,6 +21,9 @@ def run(shape, mode, reps=2):
     if mode == "metis":
         Q = ref.metis_order(A)
         relax = -1
+    elif mode == "metis-child":
+        Q = ref.metis_order_child(A)
+        relax = -1
     elif mode == "nd-cholmod":
         Q = problems.nested_dissection(shape, leaf=8)
         relax = -1
@@ -49,7 +52,7 @@ if __name__ == "__main__":
     todo = sys.argv[1:] or ["1024x1024", "64x64x64", "96x96x96"]
     for s in todo:
         shape = tuple(int(x) for x in s.split("x"))
-        for mode in ("standin", "nd-cholmod", "metis"):
+        for mode in os.environ.get("PROBE_MODES", "standin,nd-cholmod,metis").split(","):
             run(shape, mode)
         from suitesparse_amd import _lib
         _lib.lib().spqrgpu_amd_finalize()

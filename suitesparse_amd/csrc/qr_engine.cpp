@@ -1932,6 +1932,34 @@ extern "C" int gpuqr_factor_sparse
 
 extern "C" hipError_t qr_scratch_address (void **ptr, size_t *bytes) ;
 
+// GPUQR_BACKTRACE=1: a fatal signal in the host code prints the native call stack (return addresses
+// relative to the libraries' load addresses, resolvable with llvm-symbolizer) before the default action.
+// A debugging aid for machines without a debugger; installed when the library is loaded.
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+static void fatal_signal_backtrace (int sig)
+{
+    void *frames [64] ;
+    const int n = backtrace (frames, 64) ;
+    const char msg [] = "[gpuqr] fatal signal, native backtrace:\n" ;
+    (void) !write (2, msg, sizeof (msg) - 1) ;
+    backtrace_symbols_fd (frames, n, 2) ;
+    signal (sig, SIG_DFL) ;
+    raise (sig) ;
+}
+__attribute__ ((constructor)) static void install_backtrace_handler (void)
+{
+    const char *e = getenv ("GPUQR_BACKTRACE") ;
+    if (e && *e && *e != '0')
+    {
+        void *warm [2] ; (void) backtrace (warm, 2) ;       // loads the unwinder now, not inside the handler
+        signal (SIGSEGV, fatal_signal_backtrace) ;
+        signal (SIGBUS, fatal_signal_backtrace) ;
+        signal (SIGABRT, fatal_signal_backtrace) ;
+    }
+}
+
 // Per-device set-up of everything the engine keeps between calls: streams, events, the kernels'
 // attributes, and the address of the device's copy of the fixed workspace.  Whatever must be created
 // is created here, so that gpuqr_factor_sparse_noalloc itself creates nothing.

@@ -510,6 +510,24 @@ struct PinnedStackCache
 } ;
 static PinnedStackCache g_pinned_stack ;
 
+// The largest R stack this driver asks the system to page-lock (GPUQR_PIN_LIMIT_GIB, default 48); a
+// larger one is pageable and filled through bounce buffers.  Systems refuse pinned memory beyond some
+// total (64 GB on the machine this was developed on), and an allocation just above that total does not
+// fail: 70.4 GB were granted after a second, and the process then died inside the runtime when its
+// first copy went to create a hardware queue (the 87 GB of a larger problem are refused at once and
+// harmlessly).  Asking only for what leaves the runtime room avoids both.
+static size_t pin_limit_bytes (void)
+{
+    static size_t limit = 0 ;
+    if (limit == 0)
+    {
+        const char *e = getenv ("GPUQR_PIN_LIMIT_GIB") ;
+        const double gib = (e && atof (e) > 0) ? atof (e) : 48.0 ;
+        limit = (size_t) (gib * 1073741824.0) ;
+    }
+    return limit ;
+}
+
 extern "C" void spqr_amd_numeric_free (spqr_amd_numeric *num)
 {
     if (!num) return ;
@@ -791,6 +809,7 @@ static int factorize_impl
             num->Rstack = Rstack_user ;
             num->RstackBorrowed = 1 ;
             if (rtotal > 0 && getenv ("GPUQR_PAGEABLE_R") == NULL
+                && (size_t) rtotal * sizeof (double) <= pin_limit_bytes ( )
                 && hipHostRegister (Rstack_user, (size_t) rtotal * sizeof (double), hipHostRegisterDefault) == hipSuccess)
                 registered = true ;
             else { (void) hipGetLastError ( ) ; num->RstackPinned = 0 ; }
@@ -803,12 +822,14 @@ static int factorize_impl
         }
         else
         if (getenv ("GPUQR_PAGEABLE_R") == NULL && (size_t) rtotal * sizeof (double) >= ((size_t) 256 << 20)
+            && (size_t) rtotal * sizeof (double) <= pin_limit_bytes ( )
             && (pin_job.start ((size_t) rtotal * sizeof (double)), pin_job.started))
         {
             // (joined below, before the first use of the stack)
         }
         else
         if (getenv ("GPUQR_PAGEABLE_R") != NULL       // test knob: take the fallback path
+            || (size_t) rtotal * sizeof (double) > pin_limit_bytes ( )
             || hipHostMalloc ((void **) &num->Rstack, (size_t) std::max ((Long) 1, rtotal) * sizeof (double), hipHostMallocDefault) != hipSuccess)
         {
             (void) hipGetLastError ( ) ;
