@@ -57,6 +57,13 @@ DECLARED_DEVICE_MEMORY = int(float(os.environ.get("BENCH_DEVICE_GIB", "200")) * 
 T_START = time.perf_counter()
 
 
+def log(msg):
+    """Progress on stderr (the JSON line is the only thing on stdout): long phases say where they are."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write("[bench %6.1f s] %s\n" % (time.perf_counter() - T_START, msg))
+        sys.stderr.flush()
+
+
 def canon_flops(m, n):
     return 2.0 * n * n * (m - n / 3.0) if m >= n else 2.0 * m * m * (n - m / 3.0)
 
@@ -124,6 +131,7 @@ def cpu_baseline_sparse(kind, k):
     if reference_available():
         from oracle import ref
         cores = ref.threads()
+        log("CPU baseline: the reference's SuiteSparseQR on %s, %d threads ..." % ("x".join(map(str, shape)), cores))
         r = ref.spqr(A, ordering=ref.ORDERING_METIS, tol=ref.NO_TOL, symbolic=True, want_R=False)
         return {"value": r.flopcount / r.factorize_time / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "reference",
                 "sample": "%s grid %s of the same generator, METIS order: the reference's SuiteSparseQR on the host "
@@ -239,6 +247,7 @@ def time_steps(cx, step, prepare, K, W, nbuf=1):
     for i in range(W):
         prepare(i)
         step(i)
+        log("warm-up step %d of %d done" % (i + 1, W))
     for i in range(min(K, nbuf)):
         prepare(W + i)
     kernel_ms, launches = 0.0, 0
@@ -251,6 +260,7 @@ def time_steps(cx, step, prepare, K, W, nbuf=1):
         step(W + i, st, last=(i == K - 1))
         kernel_ms += st.kernelTime
         launches = st.numLaunches
+        log("timed step %d of %d done" % (i + 1, K))
     barrier()
     elapsed = time.perf_counter() - t0
     if cx.world > 1:
@@ -334,7 +344,9 @@ def run_sparse(cx, kind, k, K, W, ordering="metis", profile=True):
     t0 = time.perf_counter()
     shape = (k, k) if kind == "sparse2d" else (k, k, k)
     A = problems.stacked_ls(shape)
+    log("%s %d: matrix generated, ordering ..." % (kind, k))
     Q, order_name, order_s = column_order(cx, A, shape, ordering)
+    log("column order in %.1f s (%s), analysis ..." % (order_s, order_name.split(" ")[0]))
     t1 = time.perf_counter()
     # relax = -1: the fronts SPQR's own analysis makes for this column order (bit-identical arrays)
     sym = spqr.analyze(A, Q, relax=-1, gpuMemorySize=DECLARED_DEVICE_MEMORY)
@@ -379,6 +391,8 @@ def run_sparse(cx, kind, k, K, W, ordering="metis", profile=True):
     step(0)
     torch.cuda.synchronize()
     cold_ms = (time.perf_counter() - t0c) * 1e3
+    log("analysis %.1f s (%d fronts, %d stages, %.1f TFLOP); first factorization %.2f s" % (
+        analysis_s, sym.nf, sym.numStages, sym.flopcount / 1e12, cold_ms / 1e3))
     elapsed, kernel_ms, launches = time_steps(cx, step, prepare, K, max(W - 1, 0))
     verified = None
     if "res" in kept:
@@ -391,10 +405,12 @@ def run_sparse(cx, kind, k, K, W, ordering="metis", profile=True):
                     "seconds": None}
         res.free()
         verified["seconds"] = round(time.perf_counter() - tv, 2)
+        log("R of the last step checked: %.2e (%s)" % (err, "passed" if verified["passed"] else "FAILED"))
     elif cx.world > 1:
         verified = {"check": "not run: R is spread over the ranks (tests/test_multigpu_cpu.py and the -m gpu rank tests "
                              "compare the distributed R with the single-process one bit for bit)", "value": None, "passed": None}
     per_kernel, best = profile_step(cx, step, prepare) if profile else ({}, None)
+    log("profiled step done")
     out = dict(workload=workload, tag="%s:%d" % (kind, k), flops=sym.flopcount, elapsed=elapsed, kernel_ms=kernel_ms,
                launches=launches, per_kernel=per_kernel, best=best, scaling="strong", config=config,
                cold_ms=cold_ms, analysis_s=analysis_s, ordering_s=order_s, mapping=mapping, verified=verified,

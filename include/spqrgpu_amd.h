@@ -194,6 +194,14 @@ int spqrgpu_amd_qtmult (spqr_amd_qt *qt, const double *B, int64_t ldb, double *C
 int spqr_amd_rsolve (const spqr_amd_symbolic *sym, const spqr_amd_numeric *num, const int64_t *Qfill,
                      int64_t nacols, int64_t nrhs, const double *C, int64_t ldc, double *X);
 
+/* X = R' \ B by forward substitution on the packed R blocks of num, on the host: the multifrontal part
+ * of spqr_private_rtsolve (SPQR/Source/SuiteSparseQR_expert.cpp:367-470; SuiteSparseQR_solve with
+ * SPQR_RTX_EQUALS_B, SuiteSparseQR_definitions.h:40).  B is n-by-nrhs in the factorization's column
+ * order (ldb >= n), X rank-by-nrhs in the row order of R (ldx >= rank).  With spqr_amd_rsolve it solves
+ * the seminormal equations R'R x = A'b.  Returns 0, 1 out of memory, 3 invalid argument. */
+int spqr_amd_rtsolve (const spqr_amd_symbolic *sym, const spqr_amd_numeric *num, int64_t nrhs,
+                      const double *B, int64_t ldb, double *X, int64_t ldx);
+
 /* out = R in (transposed == 0: in has n entries in the factorization's column order, out rank entries) or
  * out = R' in (transposed != 0: in rank entries, out n entries), on the packed R blocks of num, on the
  * host.  No counterpart in the reference's library; its test suite forms R'R - (AP)'(AP) explicitly

@@ -1981,6 +1981,66 @@ extern "C" int spqr_amd_rsolve
     return 0 ;
 }
 
+// X = R' \ B by forward substitution on the packed R blocks of num, on the host: the multifrontal part of
+// spqr_private_rtsolve (SPQR/Source/SuiteSparseQR_expert.cpp:367-470, system SPQR_RTX_EQUALS_B; the
+// caller applies E' when SPQR_RTX_EQUALS_ETB is wanted).  B is n-by-nrhs in the factorization's column
+// order (leading dimension ldb >= n), X rank-by-nrhs (leading dimension ldx >= rank) in the row order
+// of R.  Fronts in increasing order: a front first takes what the fronts before it contributed to its
+// pivot columns, solves its triangle, then passes its share on to its non-pivotal columns.  Entries of
+// B in dead columns are ignored (they belong to no row of R).
+extern "C" int spqr_amd_rtsolve
+(
+    const spqr_amd_symbolic *S, const spqr_amd_numeric *num, int64_t nrhs, const double *B, int64_t ldb,
+    double *X, int64_t ldx
+)
+{
+    if (!S || !num || !num->Rstack || !num->Rblock || !num->Rdead || nrhs < 0) return 3 ;
+    if (nrhs > 0 && (!B || !X)) return 3 ;
+    const Long nf = S->nf, n = S->n, rank = num->sumfrank ;
+    if (ldb < std::max ((Long) 1, n) || ldx < std::max ((Long) 1, rank)) return 3 ;
+    for (Long f = 0 ; f < nf ; f++) if (num->Rblock [f] < 0) return 3 ;
+    try
+    {
+        hostvec<double> G ((size_t) std::max ((Long) 1, n)) ;
+        const char *Rdead = num->Rdead ;
+        for (Long kk = 0 ; kk < nrhs ; kk++)
+        {
+            for (Long j = 0 ; j < n ; j++) G [j] = B [j + kk * ldb] ;
+            double *x = X + kk * ldx ;
+            Long row1 = 0 ;
+            for (Long f = 0 ; f < nf ; f++)
+            {
+                const double *R = num->Rstack + num->Rblock [f] ;
+                const Long col1 = S->Super [f], fp = S->Super [f+1] - col1 ;
+                const Long pr = S->Rp [f], fn = S->Rp [f+1] - pr ;
+                Long rm = 0 ;
+                for (Long k = 0 ; k < fn ; k++)
+                {
+                    const bool live = (k < fp && !Rdead [col1 + k]) ;
+                    if (live) rm++ ;
+                    const Long j = S->Rj [pr + k] ;
+                    // column k of the block: rm entries, rows row1 .. row1+rm-1; the last one is the
+                    // diagonal when the column is a live pivot
+                    const Long above = live ? rm - 1 : rm ;
+                    double sum = 0 ;
+                    for (Long i = 0 ; i < above ; i++) sum += R [i] * x [row1 + i] ;
+                    if (live)
+                    {
+                        if (row1 + rm > rank) return 3 ;
+                        x [row1 + rm - 1] = (G [j] - sum) / R [rm - 1] ;
+                    }
+                    else if (j < n) G [j] -= sum ;
+                    R += rm ;
+                }
+                row1 += rm ;
+            }
+            if (row1 != rank) return 3 ;
+        }
+    }
+    catch (std::bad_alloc &) { return 1 ; }
+    return 0 ;
+}
+
 // t = R y (transposed == 0; y of size n in the factorization's column order, t of size rank) or
 // z = R' t (transposed != 0; z of size n), on the packed R blocks of num, on a few host threads.
 // The two products are what check_r_factor needs of R (SPQR/Tcov/qrtest.cpp:1218-1257 forms

@@ -204,6 +204,24 @@ def rsolve(sym, res, Cq, nacols=None, permute=True):
     return X[:n, :k].copy()
 
 
+def rtsolve(sym, res, B):
+    """spqr_amd_rtsolve: X = R' \\ B on the packed R blocks of a factorization made with keep_num
+    (SuiteSparseQR_solve with SPQR_RTX_EQUALS_B in the reference).  B is n-by-k in the factorization's
+    column order; returns X, rank-by-k, in the row order of R."""
+    L = _bind()
+    L.spqr_amd_rtsolve.restype = C.c_int
+    L.spqr_amd_rtsolve.argtypes = [C.c_void_p, C.POINTER(Numeric), C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+    n, rank = int(sym.n), int(res.rank)
+    B = np.asarray(B, dtype=np.float64).reshape(n, -1)
+    k = B.shape[1]
+    Bf = np.asfortranarray(B) if n > 0 else np.zeros((1, k), order="F")
+    X = np.zeros((max(rank, 1), max(k, 1)), order="F")
+    code = L.spqr_amd_rtsolve(sym._h, res._num, k, _p(Bf), max(n, 1), _p(X), max(rank, 1))
+    if code != 0:
+        raise RuntimeError("spqr_amd_rtsolve failed with code %d" % code)
+    return X[:rank, :k].copy()
+
+
 def rmult(sym, res, v, transposed=False):
     """spqr_amd_rmult: R v (v of size n, the factorization's column order) or R' v (v of size rank) on the
     packed R blocks of a factorization made with keep_num."""

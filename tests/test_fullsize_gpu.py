@@ -88,7 +88,7 @@ def test_factorizing_r_again_returns_r():
         assert float((R2 - R).abs().max() / R.abs().max()) <= 1e-13
 
 
-@pytest.mark.parametrize("grid,leaf", [((256, 256), 8), ((32, 32, 32), 8)])
+@pytest.mark.parametrize("grid,leaf", [((256, 256), 8), ((32, 32, 32), 8), ((1024, 1024), 8), ((64, 64, 64), 8)])
 def test_sparse_least_squares_residual_at_size(grid, leaf):
     """The checks of qrdemo_gpu.cpp:92-113 at a size the dense reference cannot follow: the solution
     from R and Q'b satisfies the normal equations, ||A'(Ax-b)|| / (||A|| ||b||) at rounding level, and
@@ -103,3 +103,56 @@ def test_sparse_least_squares_residual_at_size(grid, leaf):
     anorm = abs(A).sum(axis=0).max()
     assert np.linalg.norm(A.T @ r) <= 1e-12 * anorm * np.linalg.norm(b) * 10
     assert R.shape[0] == n + 1 and np.all(np.abs(R.diagonal()[:n]) > 0)
+
+
+
+def _bench_order(A, shape):
+    """The column order bench.py uses: the reference's METIS order when its build is here."""
+    from oracle import ref
+    from suitesparse_amd import problems
+    if ref.available():
+        return ref.metis_order_child(A)
+    return problems.nested_dissection(shape, leaf=8)
+
+
+@pytest.mark.parametrize("shape,mem_gib", [((1024, 1024), 200), ((96, 96, 96), 200), ((128, 128, 128), 200)],
+                         ids=["config3-1024x1024", "3d-96", "config4-128-staged"])
+def test_r_at_the_sizes_the_bench_times(shape, mem_gib):
+    """What bench.py times, checked at the size it is timed: the 2D 1024^2 grid (config 3), the 3D 96^3
+    grid and the 3D 128^3 grid (config 4: four stages at 200 GiB declared, the 70 GB of R on a pageable
+    stack), in the bench's column order and with SPQR's own fronts.  The check is the reference's
+    check_r_factor (SPQR/Tcov/qrtest.cpp:1218-1257: R'R against (AE)'(AE), bar 1e-10) through a random
+    vector, then the checks of qrdemo_gpu.cpp:92-113 with the right-hand side of the demo (b = ones)
+    solved by the seminormal equations with one step of refinement: rank = n and
+    ||A'(Ax - b)|| / (||A|| ||b||) at rounding level."""
+    import scipy.sparse as sp
+    from suitesparse_amd import multigpu, problems, spqr
+    A = problems.stacked_ls(shape)
+    m, n = A.shape
+    Q = _bench_order(A, shape)
+    sym = spqr.analyze(A, Q, relax=-1, gpuMemorySize=mem_gib * 2**30)
+    res = spqr.factorize(sym, multigpu._Csc(A), want_R=False, keep_num=True)
+    try:
+        assert res.rank == n
+        err = spqr.gram_probe(sym, res, A, seed=3)
+        assert err <= 1e-12, err
+        # min ||Ax - b||: R'R x = A'b on the packed blocks (two triangular solves), one refinement step
+        b = np.ones(m)
+        Qf = np.asarray(sym.Qfill)
+
+        def solve(rhs):                     # (R'R) y = rhs in the factorization's column order
+            w = spqr.rtsolve(sym, res, rhs)
+            return spqr.rsolve(sym, res, w, permute=False)[:, 0]
+
+        g = (A.T @ b)[Qf]
+        y = solve(g)
+        x = np.zeros(n)
+        x[Qf] = y
+        r = b - A @ x
+        y += solve((A.T @ r)[Qf])
+        x[Qf] = y
+        r = A @ x - b
+        anorm = abs(A).sum(axis=0).max()
+        assert np.linalg.norm(A.T @ r) <= 1e-12 * anorm * np.linalg.norm(b) * 10
+    finally:
+        res.free()

@@ -424,6 +424,13 @@ def test_rsolve_on_packed_blocks_without_a_gpu():
     assert np.abs(spqr.rmult(sym, Res, v) - R @ v).max() <= 1e-13 * np.abs(R @ v).max()
     assert np.abs(spqr.rmult(sym, Res, v, transposed=True) - R.T @ v).max() <= 1e-13 * np.abs(R.T @ v).max()
     assert spqr.gram_probe(sym, Res, A) <= 1e-13
+    # R' \ B, and with it the seminormal equations R'R x = A'b
+    g = rng.standard_normal((n, 2))
+    wt = spqr.rtsolve(sym, Res, g)
+    assert np.abs(R.T @ wt - g).max() <= 1e-12 * np.abs(g).max()
+    xs = np.zeros((n, 3))
+    xs[sym.Qfill] = spqr.rsolve(sym, Res, spqr.rtsolve(sym, Res, (A.T @ b)[sym.Qfill]), permute=False)
+    assert np.abs(xs - xl).max() <= 1e-10 * np.abs(xl).max()
     # a numeric object that holds only a part of R is refused
     Rblock[nf // 2] = -1
     with pytest.raises(RuntimeError):

@@ -17,7 +17,7 @@ CASES = [
     ("grid:72x72", rc.ORD_COLAMD, 0), ("grid:128x128", rc.ORD_AMD, 2**34), ("grid:256x256", rc.ORD_METIS, 2**34),
     ("grid:6x6x6", rc.ORD_COLAMD, 0), ("grid:10x10x10", rc.ORD_METIS, 2**34), ("grid:14x14x14", rc.ORD_METIS, 3 * 2**20),
     ("grid:20x17x9", rc.ORD_AMD, 2**34), ("grid:24x24x24", rc.ORD_METIS, 2**34), ("grid:32x32x32", rc.ORD_METIS, 2**34),
-    ("grid:32x32x32", rc.ORD_COLAMD, 64 * 2**20),
+    ("grid:32x32x32", rc.ORD_COLAMD, 2**30),
     ("ash219:", rc.ORD_COLAMD, 2**34), ("rand:300x120x7", rc.ORD_COLAMD, 2**34), ("rand:500x400x3", rc.ORD_AMD, 0),
 ]
 
