@@ -164,6 +164,13 @@ void gpuqr_replay_free (gpuqr_replay *rp);
  * (GPUQREngine/Source/TaskDescriptor/TaskDescriptor_flops.cpp:70-104). */
 int64_t gpuqr_front_flops (int64_t fm, int64_t fn, const int64_t *Stair);
 
+/* Device memory the engine itself allocates for one fm-by-fn front beyond the front (task records,
+ * workgroup list, VT tiles), an upper bound.  The reference prices its queue and VT pools inside
+ * spqrgpu_computeFrontStaging (SPQR/SPQRGPU/spqrgpu_computeFrontStaging.cpp:90-118,161-164) with the
+ * sizes of ITS scheduler; this engine's differ, and a driver that must fit a stage into real memory asks
+ * here. */
+int64_t gpuqr_front_workspace_bytes (int64_t fm, int64_t fn);
+
 /* The per-task counts that sum is made of: the reference's formulas flopsFactorizeVT / flopsFactorize /
  * flopsApply (TaskDescriptor_flops.cpp:18-28, :34-42, :48-53) evaluated at the task's own dimensions.
  * On the reference's tile shapes (m = 32*numTiles rows, n = 32 columns, k = 32 reflectors) they are the

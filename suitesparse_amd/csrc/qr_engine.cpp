@@ -535,6 +535,40 @@ static void plan_front
     }
 }
 
+// Device memory the engine itself takes for one fm-by-fn front (full staircase: an upper bound): a
+// 128-byte record per task, 8 bytes per workgroup of an update task, one 8 KB VT tile per panel task
+// that somebody applies.  Counted the way plan_front cuts the work (256-row chunks, merges of 8,
+// 128-column update blocks), in closed form per panel.  A caller that must fit a batch of fronts into a
+// given amount of memory adds this to the fronts themselves.
+extern "C" int64_t gpuqr_front_workspace_bytes (int64_t fm, int64_t fn)
+{
+    if (fm <= 0 || fn <= 0) return 0 ;
+    const int64_t mn = (fm < fn) ? fm : fn ;
+    const int64_t npanels = (mn + QR_PANEL_W - 1) / QR_PANEL_W ;
+    int64_t tasks = 0, refs = 0, vts = 0 ;
+    for (int64_t p = 0 ; p < npanels ; p++)
+    {
+        const int64_t c0 = p * QR_PANEL_W ;
+        const int64_t w = (fn - c0 < QR_PANEL_W) ? (fn - c0) : QR_PANEL_W ;
+        const int64_t m = fm - c0 ;
+        int64_t nodes = 0 ;
+        for (int64_t t = (m + QR_MAX_K - 1) / QR_MAX_K ; ; t = (t + QR_MAX_SEG - 1) / QR_MAX_SEG)
+        {
+            nodes += t ;
+            if (t <= 1) break ;
+        }
+        const int64_t trailing = fn - c0 - w ;
+        tasks += nodes ;
+        if (trailing > 0)
+        {
+            tasks += nodes ; vts += nodes ;
+            refs += nodes * ((trailing + 127) / 128 + 1) ;
+        }
+        refs += nodes ;
+    }
+    return tasks * (int64_t) sizeof (QrTask) + refs * (int64_t) sizeof (QrRef) + vts * (int64_t) (QR_VT_DOUBLES * sizeof (double)) ;
+}
+
 extern "C" int64_t gpuqr_front_flops (int64_t fm, int64_t fn, const int64_t *Stair)
 {
     try

@@ -892,12 +892,84 @@ static int factorize_impl
         }
 
         // ---- groups ------------------------------------------------------------------------------
+        // Without a subset the groups are the stages of the symbolic analysis (the reference's
+        // arithmetic, bit for bit).  That arithmetic prices the reference's scheduler, not this engine,
+        // and the declared memory may be all the device has (SPQR/Demo/qrdemo_gpu.cpp:34-35 declares
+        // what cudaMemGetInfo reports): when the largest stage does not fit what the device can give
+        // here and now, the fronts are cut again, greedily in postorder like a subset's, with every
+        // front priced by what this driver and this engine really allocate for it.  Contribution blocks
+        // then cross more group boundaries; R does not change (the arithmetic of a front does not depend
+        // on its group).
         hostvec<Long> grp ((size_t) std::max ((Long) 1, nf), -1) ;
         Long ngroups = 0 ;
+        bool by_stage = !mine ;          // groups = stages: the fronts of a group are Post [Stagingp [g] .. Stagingp [g+1])
+        auto front_need = [&] (Long f)
+        {
+            // the front, its S entries, its packed R (two blocks take turns), the engine's records and tiles
+            return (size_t) (Fm [f] * pitch [f]) * 8 + (size_t) S_count (f) * 16 + (size_t) rsize_of (f) * 16
+                + (size_t) gpuqr_front_workspace_bytes (Fm [f], Rp [f+1] - Rp [f]) ;
+        } ;
+        auto greedy_groups = [&] (size_t mem, bool one_each)
+        {
+            size_t acc = 0 ;
+            Long g = 0 ;
+            bool open = false ;
+            for (Long k = 0 ; k < nf ; k++)
+            {
+                const Long f = Post [k] ;
+                grp [f] = -1 ;
+                if (mine && !mine [f]) continue ;
+                size_t need = front_need (f) ;
+                size_t kids_here = 0 ;      // blocks of children in the open group: they would have to be copied in
+                for (Long cp = Childp [f] ; cp < Childp [f+1] ; cp++)
+                {
+                    const Long c = Child [cp] ;
+                    if (!((!mine || mine [c]) && grp [c] == g && open)) need += (size_t) c_size (c) * 8 ;
+                    else kids_here += (size_t) c_size (c) * 8 ;
+                }
+                if (open && (one_each || acc + need >= mem))
+                {
+                    g++ ; acc = 0 ; need += kids_here ;
+                }
+                grp [f] = g ; acc += need ; open = true ;
+            }
+            return open ? g + 1 : (Long) 0 ;
+        } ;
         if (!mine)
         {
             for (Long f = 0 ; f < nf ; f++) grp [f] = S->StageMap [f] ;
             ngroups = S->numStages ;
+            // what the largest stage takes, against what the device has for it
+            size_t worst = 0 ;
+            {
+                hostvec<size_t> per ((size_t) std::max ((Long) 1, ngroups), (size_t) 0) ;
+                for (Long f = 0 ; f < nf ; f++)
+                {
+                    const Long g = grp [f] ;
+                    if (g < 0 || g >= ngroups) continue ;
+                    per [g] += front_need (f) ;
+                    const Long pid = Parent [f] ;
+                    if (pid < nf && grp [pid] != g) per [grp [pid]] += (size_t) c_size (f) * 8 ;   // waits, then is copied in
+                }
+                for (Long g = 0 ; g < ngroups ; g++) worst = std::max (worst, per [g]) ;
+            }
+            size_t free_b = 0, total_b = 0 ;
+            if (hipMemGetInfo (&free_b, &total_b) != hipSuccess) { (void) hipGetLastError ( ) ; free_b = total_b = 0 ; }
+            // the workspaces this driver already holds are reused, what the engine holds is not counted
+            // (it may have to grow); a margin for the runtime's own needs and for blocks waiting on the device
+            const size_t held = dF.cap + dS.cap + WS.dR.cap + WS.dR2.cap ;
+            const size_t margin = (size_t) 1 << 30 ;
+            size_t room = free_b + held ;
+            room = (room > margin) ? room - margin : 0 ;
+            static const char *force = getenv ("GPUQR_REGROUP_BYTES") ;       // test knob: regroup at this many bytes
+            if (force && atof (force) > 0) room = std::min (room, (size_t) atof (force)) ;
+            if (total_b > 0 && nf > 0 && worst > room)
+            {
+                if (verbose) fprintf (stderr, "  [spqrgpu] largest stage needs %.2f GB, the device has %.2f GB: fronts grouped again\n",
+                    (double) worst / 1e9, (double) room / 1e9) ;
+                by_stage = false ;
+                ngroups = greedy_groups ((size_t) (0.92 * (double) room), false) ;
+            }
         }
         else
         {
@@ -906,29 +978,7 @@ static int factorize_impl
             const size_t reserve [4] = { 2 * gpuqr_max_queue_size (mem) * 104, (size_t) S->RimapSize * sizeof (int),
                 (size_t) S->RjmapSize * sizeof (int), (size_t) 1024 * 1024 } ;
             for (int k = 0 ; k < 4 ; k++) if (mem > 1) mem = (mem > reserve [k]) ? (mem - reserve [k]) : 0 ;
-            size_t acc = 0 ;
-            Long g = 0 ;
-            bool open = false ;
-            for (Long k = 0 ; k < nf ; k++)
-            {
-                const Long f = Post [k] ;
-                if (!mine [f]) continue ;
-                size_t need = (size_t) (Fm [f] * pitch [f]) * 8 + (size_t) S_count (f) * 16
-                    + (size_t) rsize_of (f) * 8 + (size_t) (((Fm [f] + 31) / 32) * 1024) * 8 ;
-                size_t kids_here = 0 ;      // blocks of children in the open group: they would have to be copied in
-                for (Long cp = Childp [f] ; cp < Childp [f+1] ; cp++)
-                {
-                    const Long c = Child [cp] ;
-                    if (!(mine [c] && grp [c] == g && open)) need += (size_t) c_size (c) * 8 ;
-                    else kids_here += (size_t) c_size (c) * 8 ;
-                }
-                if (open && (S->gpuMemorySize == 0 || acc + need >= mem))
-                {
-                    g++ ; acc = 0 ; need += kids_here ;
-                }
-                grp [f] = g ; acc += need ; open = true ;
-            }
-            ngroups = open ? g + 1 : 0 ;
+            ngroups = greedy_groups (mem, S->gpuMemorySize == 0) ;
         }
         if (keep && (ngroups != 1 || mine || rp)) { code = 3 ; goto done ; }      // H is kept for single-stage factorizations only
 
@@ -941,7 +991,7 @@ static int factorize_impl
         auto layout_group = [&] (Long g, bool final_pass)
         {
             list.clear ( ) ;
-            if (mine) { for (Long k = 0 ; k < nf ; k++) if (grp [Post [k]] == g) list.push_back (Post [k]) ; }
+            if (!by_stage) { for (Long k = 0 ; k < nf ; k++) if (grp [Post [k]] == g) list.push_back (Post [k]) ; }
             else for (Long p = S->Stagingp [g] ; p < S->Stagingp [g+1] ; p++) list.push_back (Post [p]) ;
             const Long numFronts = (Long) list.size ( ) ;
             FOff.assign ((size_t) numFronts, 0) ; SOff.assign ((size_t) numFronts, 0) ; ROff.assign ((size_t) numFronts, 0) ;

@@ -19,3 +19,23 @@ try:
     import torch  # noqa: F401
 except ImportError:
     pass
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _release_device_workspaces_between_modules():
+    """The library keeps its device workspaces (grow-only, up to the declared device memory) for the
+    next call.  A test module that starts child processes on the same GPU needs that memory back: a
+    process that finds the device full dies inside the runtime at its first copy instead of getting an
+    error.  So every module hands the workspaces back when it is done."""
+    yield
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return
+        from suitesparse_amd import _lib
+        L = _lib.lib()
+        L.spqrgpu_amd_finalize()
+        L.gpuqr_finalize()
+        torch.cuda.empty_cache()
+    except Exception:
+        pass
