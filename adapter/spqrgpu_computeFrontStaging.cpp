@@ -10,11 +10,15 @@
 // This fork's signature carries the symbolic object as well (EXCLUDE_ALLOCATION_TIME, set in
 // SPQR/Include/spqr.hpp:11): its version allocates the engine's workspaces into QRsym here
 // (spqrgpu_computeFrontStaging.cpp:251-281) so that their allocation is not timed with the
-// factorization.  The AMD driver keeps its device workspaces per device between calls by itself, so
-// the pointers stay NULL and only the sizes are recorded.
+// factorization.  The AMD driver keeps its device workspaces per device between calls by itself; what
+// it wants to live as long as QRsym is its own symbolic object (a copy of QRsym's arrays, plus the
+// assembly maps, the S permutation and the engine's schedule once the first factorization has made
+// them).  It is created here, kept in QRsym->wsMondoF, found there by spqrgpu_kernel, and released by
+// the Workspace::destroy that spqr_1factor.cpp:643-655 already calls on that field.
 
 #ifdef SUITESPARSE_HIP
 
+#include <new>
 #include "spqr.hpp"
 #include "spqrgpu_amd.h"
 
@@ -58,6 +62,23 @@ void spqrgpu_computeFrontStaging
     QRsym->fronts [0] = QRsym->fronts [1] = NULL ;
     QRsym->wsMondoF = QRsym->wsMondoR [0] = QRsym->wsMondoR [1] = NULL ;
     QRsym->wsMondoS = QRsym->wsRimap = QRsym->wsRjmap = QRsym->wsS = NULL ;
+    spqr_gpu *QRgpu = QRsym->QRgpu ;
+    if (QRgpu != NULL)
+    {
+        // (QRsym's own arrays are complete by now, spqr_analyze.cpp:1104; the staging is what was just computed)
+        int status = 0 ;
+        spqr_amd_symbolic *sym = spqr_amd_symbolic_from_arrays (QRsym->m, QRsym->n, QRsym->anz, numFronts,
+            QRsym->Sp, QRsym->Sj, QRsym->Sleft, QRsym->Super, QRsym->Rp, QRsym->Rj,
+            QRsym->Parent, QRsym->Childp, QRsym->Child, QRsym->Post, QRsym->Fm, QRsym->Cm,
+            QRgpu->RimapOffsets, RimapSize, QRgpu->RjmapOffsets, RjmapSize,
+            *numStages, Stagingp, StageMap, cc->gpuMemorySize, &status) ;
+        if (sym != NULL)
+        {
+            QRsym->wsMondoF = new (std::nothrow) Workspace (sym, [] (void *p) { spqr_amd_symbolic_free ((spqr_amd_symbolic *) p) ; }) ;
+            if (QRsym->wsMondoF == NULL) spqr_amd_symbolic_free (sym) ;
+        }
+        // (without it spqrgpu_kernel makes a short-lived one per call)
+    }
 #endif
 }
 

@@ -31,11 +31,22 @@ void spqrgpu_kernel (spqr_blob <double> *Blob)
     const Long nf = QRsym->nf ;
     const Long stack = 0 ;                      // no mixing of GPU and TBB parallelism
 
-    // The symbolic object of the AMD driver: a copy of the arrays above.  A caller that factorizes
-    // many matrices on one QRsym keeps it (for instance in a slot beside QRsym->QRgpu): the driver
-    // then reuses the assembly maps, the S permutation and the engine's schedule between calls.
+    // The symbolic object of the AMD driver: a copy of the arrays above that also keeps the assembly
+    // maps, the S permutation and the engine's schedule between calls.  This fork's analysis made it at
+    // symbolic time and keeps it in QRsym->wsMondoF (adapter/spqrgpu_computeFrontStaging.cpp; released
+    // by spqr_1factor.cpp:643-655); a stock SPQR 4.5.5, whose spqr_symbolic has no such field, gets a
+    // short-lived one here.
     int status = 0 ;
-    spqr_amd_symbolic *sym = spqr_amd_symbolic_from_arrays (QRsym->m, QRsym->n, QRsym->anz, nf,
+    spqr_amd_symbolic *sym = NULL ;
+    bool own_sym = true ;
+#ifdef EXCLUDE_ALLOCATION_TIME
+    if (QRsym->wsMondoF != NULL && QRsym->wsMondoF->payload != NULL)
+    {
+        sym = (spqr_amd_symbolic *) QRsym->wsMondoF->payload ;
+        own_sym = false ;
+    }
+#endif
+    if (sym == NULL) sym = spqr_amd_symbolic_from_arrays (QRsym->m, QRsym->n, QRsym->anz, nf,
         QRsym->Sp, QRsym->Sj, QRsym->Sleft, QRsym->Super, QRsym->Rp, QRsym->Rj,
         QRsym->Parent, QRsym->Childp, QRsym->Child, QRsym->Post, QRsym->Fm, QRsym->Cm,
         QRgpu->RimapOffsets, QRgpu->RimapSize, QRgpu->RjmapOffsets, QRgpu->RjmapSize,
@@ -51,7 +62,7 @@ void spqrgpu_kernel (spqr_blob <double> *Blob)
     Long *Rblock_offset = (Long *) cholmod_l_malloc (MAX (nf, 1), sizeof (Long), cc) ;
     if (cc->status < CHOLMOD_OK)
     {
-        spqr_amd_symbolic_free (sym) ;
+        if (own_sym) spqr_amd_symbolic_free (sym) ;
         return ;
     }
 
@@ -71,7 +82,7 @@ void spqrgpu_kernel (spqr_blob <double> *Blob)
         cc->gpuNumKernelLaunches = launches ;
     }
     cholmod_l_free (MAX (nf, 1), sizeof (Long), Rblock_offset, cc) ;
-    spqr_amd_symbolic_free (sym) ;
+    if (own_sym) spqr_amd_symbolic_free (sym) ;
     // (the reference ignores the engine's return code, spqrgpu_kernel.cpp:638; here a failure reaches cc)
     if (code == 1) ERROR (CHOLMOD_OUT_OF_MEMORY, "out of memory") ;
     else if (code != 0) ERROR (CHOLMOD_GPU_PROBLEM, "GPU factorization failed") ;

@@ -25,10 +25,32 @@
 typedef long Int ;                      // SuiteSparse_long
 #endif
 
-// SuiteSparse_GPURuntime's buffer class.  The engine has no use for it (it calls hipMalloc directly), but
-// this fork's spqr_symbolic keeps pointers to preallocated ones (SPQR/Include/SuiteSparseQR.hpp:208-219),
-// so the name must exist for that header to compile against this one.
-class Workspace ;
+// SuiteSparse_GPURuntime's buffer class (SuiteSparse_GPURuntime/Include/SuiteSparseGPU_Workspace.hpp:10-108).
+// The engine has no use for buffers of that kind (it calls hipMalloc directly), but this fork's
+// spqr_symbolic keeps pointers to workspaces that its spqrgpu_computeFrontStaging allocates at symbolic
+// time (SPQR/Include/SuiteSparseQR.hpp:208-219, SPQR/SPQRGPU/spqrgpu_computeFrontStaging.cpp:251-286)
+// and that spqr_1factor lets go of with Workspace::destroy once the numeric factorization is done
+// (SPQR/Source/spqr_1factor.cpp:643-655).  That lifetime is what the AMD driver's own symbolic object
+// wants too (assembly maps, S permutation, the engine's schedule live in it), so the class here is a
+// handle with exactly that protocol: something to keep, and how to let go of it.
+class Workspace
+{
+public:
+    void *payload ;
+    void (*release) (void *) ;
+    Workspace (void *payload_arg, void (*release_arg) (void *)) : payload (payload_arg), release (release_arg) { }
+    void *cpu ( ) { return payload ; }
+    void *gpu ( ) { return NULL ; }
+    static Workspace *destroy (Workspace *address)
+    {
+        if (address)
+        {
+            if (address->release && address->payload) address->release (address->payload) ;
+            delete address ;
+        }
+        return NULL ;
+    }
+} ;
 #ifndef EMPTY
 #define EMPTY (-1)
 #endif

@@ -52,6 +52,23 @@ void call_them (spqr_blob <double> *Bd, spqr_blob <Complex> *Bc, cholmod_common 
         cc) ;
     spqrgpu_buildAssemblyMaps (0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0) ;
 }
+#ifdef EXCLUDE_ALLOCATION_TIME
+// what SPQR/Source/spqr_1factor.cpp:643-655 does with the workspaces of the symbolic object once the
+// numeric factorization is done, statement for statement: it must compile against this repository's
+// GPUQREngine.hpp, because that is where the AMD driver's symbolic object is released
+void release_them (spqr_symbolic *QRsym, cholmod_common *cc)
+{
+    QRsym->wsMondoS = Workspace::destroy(QRsym->wsMondoS);
+    QRsym->wsRjmap  = Workspace::destroy(QRsym->wsRjmap);
+    QRsym->wsRimap  = Workspace::destroy(QRsym->wsRimap);
+    QRsym->fronts[0] = (Front*) cholmod_l_free (QRsym->maxfronts_in_stage, sizeof(Front), QRsym->fronts[0], cc) ;
+    if (QRsym->fronts[1] != NULL) QRsym->fronts[1] = (Front*) cholmod_l_free (QRsym->maxfronts_in_stage, sizeof(Front), QRsym->fronts[1], cc) ;
+    QRsym->wsMondoF = Workspace::destroy(QRsym->wsMondoF);
+    QRsym->wsMondoR[0] = Workspace::destroy(QRsym->wsMondoR[0]);
+    if (QRsym->wsMondoR[1] != NULL) QRsym->wsMondoR[1] = Workspace::destroy(QRsym->wsMondoR[1]);
+    QRsym->wsS = Workspace::destroy(QRsym->wsS);
+}
+#endif
 """
 
 
