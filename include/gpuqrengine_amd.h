@@ -164,6 +164,13 @@ void gpuqr_replay_free (gpuqr_replay *rp);
  * (GPUQREngine/Source/TaskDescriptor/TaskDescriptor_flops.cpp:70-104). */
 int64_t gpuqr_front_flops (int64_t fm, int64_t fn, const int64_t *Stair);
 
+/* Debugging mode: every kernel launch is waited for and checked before the next one is issued, and a
+ * failure is reported with its round and kernel (stderr) and ends the call with GPUQR_GPUERROR: what
+ * the reference builds with -DFORCE_SYNCHRONIZE (GPUQREngine/Source/Scheduler/Scheduler_LaunchKernel.cpp:
+ * 55-58).  Also switched on by GPUQR_SERIAL=1 in the environment.  Results are bit-identical to the
+ * normal mode's (same tasks, same order within a stream). */
+void gpuqr_set_serial (int on);
+
 /* Device memory the engine itself allocates for one fm-by-fn front beyond the front (task records,
  * workgroup list, VT tiles), an upper bound.  The reference prices its queue and VT pools inside
  * spqrgpu_computeFrontStaging (SPQR/SPQRGPU/spqrgpu_computeFrontStaging.cpp:90-118,161-164) with the

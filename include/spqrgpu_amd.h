@@ -64,8 +64,17 @@ typedef struct spqr_amd_symbolic spqr_amd_symbolic;
  * in for spqr_analyze (SPQR/Source/spqr_analyze.cpp:75-1130) on a machine
  * without CHOLMOD; an SPQR build passes its own QRsym arrays to the functions
  * above instead.  A is m-by-n in compressed-column form, Quser a column
- * permutation or NULL.  *status: 0 ok, 1 out of memory, 2 staging infeasible,
- * 3 invalid input. */
+ * permutation or NULL.  relax < 0: the arrays SPQR itself would build for the
+ * column order Quser (spqr_analyze with SPQR_ORDERING_GIVEN, the call
+ * spqr_1factor.cpp:624-641 makes once spqr_1colamd has ordered the columns): no
+ * further postordering, CHOLMOD's relaxed supernodes with its default parameters
+ * (CHOLMOD/Supernodal/cholmod_super_symbolic.c:676-790), the frontal tree
+ * postordered by front width (spqr_analyze.cpp:561-611): Super, Rp, Rj, Parent,
+ * Post, Childp, Child, Sp, Sj, Sleft, PLinv, Fm, Cm and the flop count are then
+ * those of an SPQR run, entry for entry.  relax >= 0: the columns are postordered
+ * here, fundamental supernodes, merged into their parent when that adds at most
+ * relax percent of explicit zeros.  *status: 0 ok, 1 out of memory, 2 staging
+ * infeasible, 3 invalid input (Quser not a permutation included). */
 spqr_amd_symbolic *spqr_amd_analyze
 (
     int64_t m, int64_t n, const int64_t *Ap, const int64_t *Ai, const int64_t *Quser,

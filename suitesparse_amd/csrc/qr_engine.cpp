@@ -213,6 +213,15 @@ static KernelProfile g_profile [QR_NKERNELS] ;
 
 extern "C" void gpuqr_profile_enable (int on) { g_profile_on = on ; }
 extern "C" void gpuqr_profile_reset (void) { memset (g_profile, 0, sizeof (g_profile)) ; }
+// Serial debugging mode: off, on by GPUQR_SERIAL=1 in the environment or by gpuqr_set_serial (1).
+static int g_serial = -1 ;
+static inline bool serial_mode (void)
+{
+    if (g_serial < 0) { const char *e = getenv ("GPUQR_SERIAL") ; g_serial = (e && *e && *e != '0') ? 1 : 0 ; }
+    return g_serial == 1 ;
+}
+extern "C" void gpuqr_set_serial (int on) { g_serial = on ? 1 : 0 ; }
+
 extern "C" int gpuqr_profile_get (int kid, double *ms, int64_t *launches, int64_t *tasks, double *flops, double *bytes)
 {
     if (kid < 0 || kid >= QR_NKERNELS) return -1 ;
@@ -1136,6 +1145,22 @@ static int launch_rounds (DeviceCache *dc, gpuqr_front *fronts, int64_t nf, gpuq
                     }
                     launched [x] = true ;
                     launches++ ;
+                    // GPUQR_SERIAL=1 (gpuqr_set_serial): the debugging mode of the reference's
+                    // -DFORCE_SYNCHRONIZE (GPUQREngine/Source/Scheduler/Scheduler_LaunchKernel.cpp:55-58):
+                    // every launch is waited for and checked before the next one goes out, and a failure
+                    // names the launch it belongs to.
+                    if (serial_mode ( ))
+                    {
+                        hipError_t e1_ = hipStreamSynchronize (st) ;
+                        hipError_t e2_ = hipGetLastError ( ) ;
+                        if (e1_ != hipSuccess || e2_ != hipSuccess)
+                        {
+                            fprintf (stderr, "gpuqr: launch %lld failed (round %d, kernel slot %d, %lld workgroups): %s\n",
+                                (long long) launches, (int) r, kid, (long long) n,
+                                hipGetErrorString (e1_ != hipSuccess ? e1_ : e2_)) ;
+                            code = GPUQR_GPUERROR ; goto cleanup ;
+                        }
+                    }
                 }
                 for (int c = 0 ; c < QR_NCLASS ; c++)
                 {

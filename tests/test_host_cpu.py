@@ -435,3 +435,17 @@ def test_rsolve_on_packed_blocks_without_a_gpu():
     Rblock[nf // 2] = -1
     with pytest.raises(RuntimeError):
         spqr.rsolve(sym, Res, Cq)
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_host_code_under_address_and_ub_sanitizers():
+    """tests/cpp/host_asan.cpp: every host-only entry point of the library (analysis in both modes,
+    staging, assembly maps, planner counts, symbolic object from arrays and its validation, R conversion,
+    products and triangular solves on packed blocks) built with -fsanitize=address,undefined on the host
+    side and run without a GPU.  Any report of either sanitizer ends the program with a non-zero status."""
+    import subprocess
+    d = os.path.join(ROOT, "tests", "cpp")
+    subprocess.run(["make", "-s", "-C", d, "host_asan"], check=True, timeout=900)
+    r = subprocess.run([os.path.join(d, "host_asan")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0 and "all checks passed" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
