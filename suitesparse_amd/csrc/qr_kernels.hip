@@ -643,41 +643,49 @@ __device__ void packassemble (const QrPackAssembleTask &t, char *smem)
     for (int p = threadIdx.x ; p < ctm ; p += QR_THREADS) shRimap [p] = Rimap [t.cistart + p] ;
     for (int p = threadIdx.x ; p < ctn ; p += QR_THREADS) shRjmap [p] = Rjmap [t.cjstart + p] ;
     __syncthreads ( ) ;
-    // one wave per row of the tile, lanes along the (contiguous) child columns;
-    // only the upper trapezoid cj >= ci carries data (packAssemble.cu:47-55)
-    // (four rows and both halves of the tile's columns are fetched before anything is stored: eight
-    // loads in flight per lane instead of one)
+    // One wave per row of the tile, lanes along the (contiguous) child columns, two columns (16 bytes)
+    // per lane, so that one instruction fetches a whole 128-column row of the tile; only the upper
+    // trapezoid cj >= ci carries data (packAssemble.cu:47-55).  Eight rows are fetched before anything
+    // is stored (eight 16-byte loads in flight per lane).  Where the parent columns of a lane's pair are
+    // neighbours too (the column map is a run of consecutive indices except where the parent has
+    // columns of its own in between) the pair is stored with one 16-byte store.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6 ;
-    static_assert (QR_PACK_TILE == 128, "two 64-lane passes cover the columns of a tile") ;
-    for (int cil0 = wave ; cil0 < ctm ; cil0 += 16)
+    static_assert (QR_PACK_TILE == 128, "one pass of 64 lanes x 2 columns covers the columns of a tile") ;
+    const int c0 = 2 * lane, c1 = c0 + 1 ;
+    // (columns past the tile's edge are read from its last pair; ctn >= 1, and the pair before the edge
+    // is memory of the child's block unless the tile is a single column wide, which reads one double)
+    const bool one_col = (ctn < 2) ;
+    const int lc0 = one_col ? 0 : ((c1 < ctn) ? c0 : (ctn - 2)) ;
+    const int pj0 = (c0 < ctn) ? shRjmap [c0] : 0, pj1 = (c1 < ctn) ? shRjmap [c1] : -1 ;
+    const bool pair = (c1 < ctn) && (pj1 == pj0 + 1) ;
+    for (int cil0 = wave ; cil0 < ctm ; cil0 += 32)
     {
-        double v [4][2] ;
+        d2 v [8] ;
         #pragma unroll
-        for (int u = 0 ; u < 4 ; u++)
+        for (int u = 0 ; u < 8 ; u++)
         {
             // unconditional loads through clamped indices (every entry of the tile's rows is memory
             // of the child's block, also below its diagonal): no branch, no wait behind a load
             const int cil = (cil0 + 4*u < ctm) ? (cil0 + 4*u) : (ctm - 1) ;
             gcdouble *Crow = (gcdouble *) t.C + (size_t) (t.cistart + cil) * t.cld + t.cjstart ;
-            #pragma unroll
-            for (int h = 0 ; h < 2 ; h++)
-            {
-                const int cjl = (lane + 64*h < ctn) ? (lane + 64*h) : (ctn - 1) ;
-                v [u][h] = Crow [cjl] ;
-            }
+            if (one_col) { v [u].x = Crow [0] ; v [u].y = 0 ; }
+            else v [u] = *(const gd2 *) (Crow + lc0) ;
         }
         #pragma unroll
-        for (int u = 0 ; u < 4 ; u++)
+        for (int u = 0 ; u < 8 ; u++)
         {
             const int cil = cil0 + 4*u ;
             if (cil >= ctm) break ;
             const int ci = t.cistart + cil ;
             gdouble *Prow = (gdouble *) t.P + (size_t) shRimap [cil] * t.pn ;
-            #pragma unroll
-            for (int h = 0 ; h < 2 ; h++)
+            d2 val = v [u] ;
+            if (!one_col && c1 >= ctn && c0 < ctn) val.x = val.y ;     // odd width: the last pair was read one column back
+            const bool ok0 = (c0 < ctn) && (t.cjstart + c0 >= ci), ok1 = (c1 < ctn) && (t.cjstart + c1 >= ci) ;
+            if (ok0 && ok1 && pair) *(gd2 *) (Prow + pj0) = val ;
+            else
             {
-                const int cjl = lane + 64*h ;
-                if (cjl < ctn && t.cjstart + cjl >= ci) Prow [shRjmap [cjl]] = v [u][h] ;
+                if (ok0) Prow [pj0] = val.x ;
+                if (ok1) Prow [pj1] = val.y ;
             }
         }
     }

@@ -302,3 +302,20 @@ def test_schedule_switches_in_a_fresh_process(tmp_path, switch):
         assert int(z["dense_launches"]) > int(ref["dense_launches"])     # the switch did take effect
     if name == "GPUQR_NO_PIPELINE":
         assert int(z["sp_launches"]) > int(ref["sp_launches"])
+
+
+def test_serial_debug_mode_gives_the_same_bits():
+    """gpuqr_set_serial: every launch waited for and checked (the reference's -DFORCE_SYNCHRONIZE,
+    Scheduler_LaunchKernel.cpp:55-58).  Same tasks in the same order per stream: R bit for bit."""
+    from suitesparse_amd import _lib, problems, spqr
+    A = problems.stacked_ls((14, 14, 14))
+    Q = problems.nested_dissection((14, 14, 14), leaf=4)
+    sym = spqr.analyze(A, Q, relax=-1, gpuMemorySize=2**33)
+    R0 = spqr.factorize(sym, A).R
+    L = _lib.lib()
+    L.gpuqr_set_serial(1)
+    try:
+        R1 = spqr.factorize(sym, A).R
+    finally:
+        L.gpuqr_set_serial(0)
+    assert (R0 != R1).nnz == 0

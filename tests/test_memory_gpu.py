@@ -36,7 +36,7 @@ def test_declared_memory_is_all_the_device_has():
     ballast = torch.empty(free - leave, dtype=torch.uint8, device="cuda")
     try:
         free2, _ = torch.cuda.mem_get_info()
-        assert free2 <= leave + 2**28
+        assert free2 <= leave + 2**30
         sym = spqr.analyze(A, Q, relax=-1, gpuMemorySize=int(free2))
         assert sym.status == 0 and sym.numStages >= 1
         res = spqr.factorize(sym, csc)
