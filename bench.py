@@ -109,7 +109,10 @@ def column_order(cx, A, shape, want):
         return problems.nested_dissection(shape, leaf=8), "geometric nested dissection (suitesparse_amd.problems)", 0.0
     if cx.rank == 0:
         from oracle import ref
-        Q = np.ascontiguousarray(ref.metis_order_child(A), dtype=np.int64)      # (a child process: METIS takes and frees GBs of heap)
+        # (a child process by default: METIS takes and frees GBs of heap; BENCH_METIS_INPROCESS=1 runs it here,
+        # for runs under a profiler that should see one process only)
+        order = ref.metis_order if os.environ.get("BENCH_METIS_INPROCESS") else ref.metis_order_child
+        Q = np.ascontiguousarray(order(A), dtype=np.int64)
     else:
         Q = np.zeros(n, dtype=np.int64)
     if cx.world > 1:
@@ -454,6 +457,7 @@ def main():
     ap.add_argument("--copies", type=int, default=COPIES)
     ap.add_argument("--extras", default="auto", choices=["auto", "none", "all"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="leave out the extra step with events around every launch")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -488,7 +492,7 @@ def main():
         if workload == "dense":
             return run_dense(cx, K, W, args.copies)
         kind, k = workload.split(":")
-        return run_sparse(cx, kind, int(k), K, W, args.ordering, profile)
+        return run_sparse(cx, kind, int(k), K, W, args.ordering, profile and not args.no_profile)
 
     res = run(args.workload, K, W)
 

@@ -8,6 +8,7 @@
 #include <stddef.h>
 #include <vector>
 #include <new>
+#include "../../include/gpuqrengine_amd.h"
 
 // host memory through the engine's allocator hooks (qr_engine.cpp)
 extern "C" void *qr_host_malloc (size_t bytes) ;
@@ -59,6 +60,14 @@ struct spqr_amd_symbolic
         void *d_findex = NULL ;             // int64 per S entry: where it goes in its front
         void *d_aperm = NULL ;              // int64 per S entry: position of its value in the caller's Ax
         void (*release) (NumericCache *) = NULL ;
+        // What a re-factorization need not work out again (all of it follows from the symbolic object,
+        // the row pitches and the addresses of the driver's workspaces):
+        size_t stage_worst = 0 ;            // device bytes the largest stage takes
+        bool   stage_worst_known = false ;
+        uint64_t fit_gen = 0 ;              // workspace generation at which the stages were seen to fit the device
+        hostvec<gpuqr_front> fronts ;       // the front descriptors of a single-group factorization ...
+        uint64_t fronts_key = 0 ;           // ... made for the workspaces this key stands for
+        const double *fronts_rstack = NULL ;    // ... and for R blocks delivered to this stack
     } ;
     mutable NumericCache cache ;
     ~spqr_amd_symbolic ( ) { if (cache.release) cache.release (&cache) ; }

@@ -284,6 +284,9 @@ static void release_numeric_cache (spqr_amd_symbolic::NumericCache *c)
     if (c->d_aperm) (void) hipFree (c->d_aperm) ;
     c->d_Rimap = c->d_Rjmap = c->d_findex = c->d_aperm = NULL ;
     c->built = false ;
+    c->stage_worst_known = false ; c->fit_gen = 0 ;
+    c->fronts_key = 0 ; c->fronts_rstack = NULL ;
+    hostvec<gpuqr_front> ( ).swap (c->fronts) ;
 }
 
 // Maps, staircases and the destination / source of every S entry: pattern only, so done once per
@@ -559,6 +562,8 @@ struct Buf
 } ;
 
 struct Workspaces { Buf dF, dS, dR, dR2, dAx, dTasks, dPrefix, hBounce [2] ; } ;
+// Goes up whenever the driver gives device memory back: what was seen to fit before may not fit now.
+static uint64_t g_ws_gen = 1 ;
 
 // Device -> pageable host memory through two pinned bounce buffers: the DMA of one piece overlaps
 // the host threads copying the previous piece out (a direct copy into pageable memory ran at
@@ -617,6 +622,7 @@ extern "C" void spqrgpu_amd_finalize (void)
         W.hBounce [0].release ( ) ; W.hBounce [1].release ( ) ;
     }
     g_pinned_stack.clear ( ) ;
+    g_ws_gen++ ;
     if (cur >= 0) (void) hipSetDevice (cur) ;
 }
 
@@ -939,36 +945,46 @@ static int factorize_impl
         {
             for (Long f = 0 ; f < nf ; f++) grp [f] = S->StageMap [f] ;
             ngroups = S->numStages ;
-            // what the largest stage takes, against what the device has for it
-            size_t worst = 0 ;
-            {
-                hostvec<size_t> per ((size_t) std::max ((Long) 1, ngroups), (size_t) 0) ;
-                for (Long f = 0 ; f < nf ; f++)
-                {
-                    const Long g = grp [f] ;
-                    if (g < 0 || g >= ngroups) continue ;
-                    per [g] += front_need (f) ;
-                    const Long pid = Parent [f] ;
-                    if (pid < nf && grp [pid] != g) per [grp [pid]] += (size_t) c_size (f) * 8 ;   // waits, then is copied in
-                }
-                for (Long g = 0 ; g < ngroups ; g++) worst = std::max (worst, per [g]) ;
-            }
-            size_t free_b = 0, total_b = 0 ;
-            if (hipMemGetInfo (&free_b, &total_b) != hipSuccess) { (void) hipGetLastError ( ) ; free_b = total_b = 0 ; }
-            // the workspaces this driver already holds are reused, what the engine holds is not counted
-            // (it may have to grow); a margin for the runtime's own needs and for blocks waiting on the device
-            const size_t held = dF.cap + dS.cap + WS.dR.cap + WS.dR2.cap ;
-            const size_t margin = (size_t) 1 << 30 ;
-            size_t room = free_b + held ;
-            room = (room > margin) ? room - margin : 0 ;
+            // what the largest stage takes, against what the device has for it (worked out once per
+            // symbolic object; the device is asked again only after workspaces were given back)
+            spqr_amd_symbolic::NumericCache &NCm = S->cache ;
             static const char *force = getenv ("GPUQR_REGROUP_BYTES") ;       // test knob: regroup at this many bytes
-            if (force && atof (force) > 0) room = std::min (room, (size_t) atof (force)) ;
-            if (total_b > 0 && nf > 0 && worst > room)
+            if (!(NCm.fit_gen == g_ws_gen && !rp && !keep && !force))
             {
-                if (verbose) fprintf (stderr, "  [spqrgpu] largest stage needs %.2f GB, the device has %.2f GB: fronts grouped again\n",
-                    (double) worst / 1e9, (double) room / 1e9) ;
-                by_stage = false ;
-                ngroups = greedy_groups ((size_t) (0.92 * (double) room), false) ;
+                if (!NCm.stage_worst_known || rp || keep)
+                {
+                    size_t worst = 0 ;
+                    hostvec<size_t> per ((size_t) std::max ((Long) 1, ngroups), (size_t) 0) ;
+                    for (Long f = 0 ; f < nf ; f++)
+                    {
+                        const Long g = grp [f] ;
+                        if (g < 0 || g >= ngroups) continue ;
+                        per [g] += front_need (f) ;
+                        const Long pid = Parent [f] ;
+                        if (pid < nf && grp [pid] != g) per [grp [pid]] += (size_t) c_size (f) * 8 ;   // waits, then is copied in
+                    }
+                    for (Long g = 0 ; g < ngroups ; g++) worst = std::max (worst, per [g]) ;
+                    NCm.stage_worst = worst ;
+                    NCm.stage_worst_known = !(rp || keep) ;
+                }
+                const size_t worst = NCm.stage_worst ;
+                size_t free_b = 0, total_b = 0 ;
+                if (hipMemGetInfo (&free_b, &total_b) != hipSuccess) { (void) hipGetLastError ( ) ; free_b = total_b = 0 ; }
+                // the workspaces this driver already holds are reused, what the engine holds is not counted
+                // (it may have to grow); a margin for the runtime's own needs and for blocks waiting on the device
+                const size_t held = dF.cap + dS.cap + WS.dR.cap + WS.dR2.cap ;
+                const size_t margin = (size_t) 1 << 30 ;
+                size_t room = free_b + held ;
+                room = (room > margin) ? room - margin : 0 ;
+                if (force && atof (force) > 0) room = std::min (room, (size_t) atof (force)) ;
+                if (total_b > 0 && nf > 0 && worst > room)
+                {
+                    if (verbose) fprintf (stderr, "  [spqrgpu] largest stage needs %.2f GB, the device has %.2f GB: fronts grouped again\n",
+                        (double) worst / 1e9, (double) room / 1e9) ;
+                    by_stage = false ;
+                    ngroups = greedy_groups ((size_t) (0.92 * (double) room), false) ;
+                }
+                else if (!rp && !keep) NCm.fit_gen = g_ws_gen ;
             }
         }
         else
@@ -1038,7 +1054,9 @@ static int factorize_impl
         // (a pageable stack and several groups: two device blocks for R take turns, so that a helper thread
         // can copy one group's R out while the next group runs; given up when the device has no room for the second)
         bool two_r = !num->RstackPinned && ngroups > 1 ;
+        for (int attempt = 0 ; ; attempt++)
         {
+            two_r = !num->RstackPinned && ngroups > 1 ;
             Long fmax = 1, smax = 1, rmax [2] = {1, 1} ;
             for (Long g = 0 ; g < ngroups ; g++)
             {
@@ -1054,16 +1072,31 @@ static int factorize_impl
                 if (verbose) fprintf (stderr, "  [spqrgpu] no room on the device for %s (%.2f GB)\n", what, (double) bytes / 1e9) ;
                 return false ;
             } ;
-            if (!need (dF, (size_t) fmax * sizeof (double), "the fronts of the largest group")) { code = 1 ; goto done ; }
-            if (!need (dS, (size_t) smax * sizeof (gpuqr_sentry), "the S entries of the largest group")) { code = 1 ; goto done ; }
-            if (two_r && (!need (WS.dR, (size_t) rmax [0] * sizeof (double), "the packed R of a group")
+            bool ok = need (dF, (size_t) fmax * sizeof (double), "the fronts of the largest group")
+                   && need (dS, (size_t) smax * sizeof (gpuqr_sentry), "the S entries of the largest group") ;
+            if (ok && two_r && (!need (WS.dR, (size_t) rmax [0] * sizeof (double), "the packed R of a group")
                        || !need (WS.dR2, (size_t) rmax [1] * sizeof (double), "the second block of packed R")))
             {
                 WS.dR2.release ( ) ;
                 two_r = false ;
                 rmax [0] = std::max (rmax [0], rmax [1]) ;
             }
-            if (!two_r && !need (WS.dR, (size_t) rmax [0] * sizeof (double), "the packed R of the largest group")) { code = 1 ; goto done ; }
+            if (ok && !two_r) ok = need (WS.dR, (size_t) rmax [0] * sizeof (double), "the packed R of the largest group") ;
+            if (ok) break ;
+            // The stages were taken to fit (an earlier call found them to, or the estimate said so) and the
+            // device says otherwise now: everything is handed back and the fronts are grouped by what is
+            // really free.  Once; a group that still does not fit is out of memory.
+            if (attempt > 0 || mine || keep || nf == 0) { code = 1 ; goto done ; }
+            dF.release ( ) ; dS.release ( ) ; WS.dR.release ( ) ; WS.dR2.release ( ) ;
+            g_ws_gen++ ;
+            S->cache.fit_gen = 0 ;
+            size_t free_b = 0, total_b = 0 ;
+            if (hipMemGetInfo (&free_b, &total_b) != hipSuccess) { (void) hipGetLastError ( ) ; code = 1 ; goto done ; }
+            const size_t margin = (size_t) 1 << 30 ;
+            const size_t room = (free_b > margin) ? free_b - margin : 0 ;
+            if (verbose) fprintf (stderr, "  [spqrgpu] fronts grouped again for %.2f GB\n", (double) room / 1e9) ;
+            by_stage = false ;
+            ngroups = greedy_groups ((size_t) (0.85 * (double) room), false) ;
         }
         TICK ("workspace allocation") ;
 
@@ -1093,7 +1126,30 @@ static int factorize_impl
             Buf &dR = (two_r && (g & 1)) ? WS.dR2 : WS.dR ;
             double *F0 = (double *) dF.p ;
             gpuqr_sentry *S0 = (gpuqr_sentry *) dS.p ;
-            fronts.assign ((size_t) (numFronts + nlimbo), gpuqr_front ( )) ;
+            // A single group with nothing arriving from outside, on the same workspaces as the call
+            // before: the descriptors are the ones that call made (only the host address of each packed
+            // R block may have moved with the stack).
+            spqr_amd_symbolic::NumericCache &NCf = S->cache ;
+            uint64_t fronts_key = 0 ;
+            if (ngroups == 1 && nlimbo == 0 && !rp && !mine && !keep)
+            {
+                const uint64_t parts [8] = {S->uid, (uint64_t) (uintptr_t) dF.p, (uint64_t) (uintptr_t) dS.p,
+                    (uint64_t) (uintptr_t) NC.d_Rimap, (uint64_t) (uintptr_t) NC.d_Rjmap, (uint64_t) numFronts,
+                    (uint64_t) (uintptr_t) dR.p, (uint64_t) (r_in_engine ? 1 : 0)} ;
+                fronts_key = 1469598103934665603ull ;
+                for (int i = 0 ; i < 8 ; i++) for (int b = 0 ; b < 8 ; b++) { fronts_key ^= (parts [i] >> (8*b)) & 0xff ; fronts_key *= 1099511628211ull ; }
+                fronts_key |= 1 ;
+            }
+            const bool reuse_fronts = fronts_key != 0 && NCf.fronts_key == fronts_key && (Long) NCf.fronts.size ( ) == numFronts ;
+            if (!reuse_fronts) fronts.assign ((size_t) (numFronts + nlimbo), gpuqr_front ( )) ;
+            else
+            {
+                fronts.swap (NCf.fronts) ;
+                NCf.fronts_key = 0 ;
+                const double *stack_now = r_in_engine ? num->Rstack : NULL ;
+                if (NCf.fronts_rstack != stack_now)
+                    for (Long k = 0 ; k < numFronts ; k++) if (fronts [k].cpuRpack != NULL) fronts [k].cpuRpack = num->Rstack + rhead + ROff [k] ;
+            }
 
             HIPCHK (hipMemsetAsync (F0, 0, (size_t) std::max ((Long) 1, fsum) * sizeof (double), 0)) ;
             // S entries of the group, built on the device; runs of fronts that are neighbours in
@@ -1109,7 +1165,7 @@ static int factorize_impl
             }
 
             Long next_child = numFronts ;
-            for (Long k = 0 ; k < numFronts ; k++)
+            for (Long k = 0 ; k < numFronts && !reuse_fronts ; k++)
             {
                 const Long f = list [k] ;
                 const Long fm = Fm [f], fn = Rp [f+1] - Rp [f], fp = npiv_of (f) ;
@@ -1423,6 +1479,13 @@ static int factorize_impl
                 }
             }
             TICK ("R pack + copy") ;
+            if (fronts_key != 0)
+            {
+                // kept for the next factorization on this symbolic object and these workspaces
+                NCf.fronts.swap (fronts) ;
+                NCf.fronts_key = fronts_key ;
+                NCf.fronts_rstack = r_in_engine ? num->Rstack : NULL ;
+            }
 
             if (keep)
             {
