@@ -288,6 +288,31 @@ int spqrgpu_amd_factorize_subset_dev (const spqr_amd_symbolic *sym, const int64_
                                       spqr_amd_numeric **num_out);
 int64_t spqrgpu_amd_subset_csize (const spqr_amd_symbolic *sym, const char *mine);
 
+/* --- one process, several GPUs ---------------------------------------------------------------------
+ *
+ * No counterpart in the reference (its QR is single-GPU; the hook an SPQR build would use is cc->numGPU,
+ * CHOLMOD/Include/cholmod_core.h:988, and its multi-GPU Cholesky drives one host thread per device,
+ * CHOLMOD/GPU/t_initialize_subtree.c:671-678).
+ *
+ * spqr_amd_map_tree maps the assembly tree onto nparts devices proportionally to the flops: owner[f] =
+ * the part that factorizes front f (a front whose subtree spans several parts goes to the first of
+ * them), level[f] = the number of owner changes below f; the fronts (part, level) form one call of the
+ * subset driver, which needs blocks from calls of lower levels only.  Optional outputs: the share of the
+ * flops in fronts whose subtree spans several parts, and the speed-up bound total / critical path that
+ * the mapping allows.  Returns 0, 1 out of memory, 3 invalid argument.
+ *
+ * spqrgpu_amd_factorize_multi runs that schedule from one process: one host thread per device, one
+ * spqrgpu_amd_factorize_subset_dev call per (part, level), contribution blocks whose parent lives on
+ * another device copied device to device (hipMemcpyPeer), everything else staying where it is.
+ * devices[k] = HIP device of part k (NULL: 0 .. ndev-1); parts may share a device (they then take turns
+ * on it).  The result is one numeric object holding all of R on a pageable host stack, as
+ * spqrgpu_amd_factorize leaves it; R is the single-device R bit for bit.  sym must have been analysed
+ * without rank detection.  Return codes as spqrgpu_amd_factorize. */
+int spqr_amd_map_tree (const spqr_amd_symbolic *sym, int nparts, int64_t *owner, int64_t *level,
+                       double *top_flops_share, double *speedup_bound);
+int spqrgpu_amd_factorize_multi (const spqr_amd_symbolic *sym, const int64_t *Ap, const int64_t *Ai,
+                                 const double *Ax, int ndev, const int *devices, spqr_amd_numeric **num_out);
+
 #ifdef __cplusplus
 }
 #endif

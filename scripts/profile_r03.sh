@@ -8,6 +8,9 @@ OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out/prof_r03
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export BENCH_METIS_INPROCESS=1
+# with tens of thousands of launches queued behind each other the profiler's counter collection
+# segfaults inside a launch (the same command runs through without it); the counter passes therefore
+# wait for the device every 512 launches (per-launch byte counts do not depend on that)
 PASS=${1:-kt}
 WL=${2:-sparse3d:128}
 TAG=$(echo $WL | tr ':' '_')
@@ -22,12 +25,14 @@ kt)
   python3 $S gaps "$(db /tmp/p_kt)" > "$OUT/${TAG}_queue_gaps.txt" ;;
 fw)
   rm -rf /tmp/p_f /tmp/p_w
+  export GPUQR_SYNC_EVERY=${GPUQR_SYNC_EVERY:-512}
   timeout -s KILL 550 rocprofv3 --pmc FETCH_SIZE -d /tmp/p_f -- python3 $B --no-profile > "$OUT/${TAG}_f_line.json" 2> "$OUT/${TAG}_f.err"
   date
   timeout -s KILL 550 rocprofv3 --pmc WRITE_SIZE -d /tmp/p_w -- python3 $B --no-profile > "$OUT/${TAG}_w_line.json" 2> "$OUT/${TAG}_w.err"
   python3 $S pmc "$(db /tmp/p_f)" "$(db /tmp/p_w)" "$OUT/${TAG}_pmc_traffic.json" "$OUT/${TAG}_pmc_traffic.md" "$WL" \
     "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --workload $WL --steps 1 --warmup 1 --extras none --no-cpu-baseline --no-profile" ;;
 m)
+  export GPUQR_SYNC_EVERY=${GPUQR_SYNC_EVERY:-512}
   timeout -s KILL 1000 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVES -d /tmp/p_m -- python3 $B --no-profile > "$OUT/${TAG}_m_line.json" 2> "$OUT/${TAG}_m.err"
   python3 $S counters "$(db /tmp/p_m)" "$OUT/${TAG}_pmc_mfma.md" ;;
 esac

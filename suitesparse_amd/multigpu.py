@@ -417,3 +417,54 @@ def blocks_to_csc(sym, Rblocks):
                                Rp.ctypes.data, Ri.ctypes.data, Rx.ctypes.data)
     rows = int(sum(min(int(sym.Fm[f]), int(sym.Super[f + 1] - sym.Super[f])) for f in range(nf)))
     return sp.csc_matrix((Rx[:Rp[n]], Ri[:Rp[n]], Rp), shape=(rows, n))
+
+
+def map_tree_c(sym, nparts):
+    """spqr_amd_map_tree: the same mapping made by the library (what spqrgpu_amd_factorize_multi uses).
+    Returns (owner, level, top_flops_share, speedup_bound)."""
+    L = spqr._bind()
+    L.spqr_amd_map_tree.restype = C.c_int
+    L.spqr_amd_map_tree.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    nf = int(sym.nf)
+    owner = np.zeros(max(nf, 1), np.int64)
+    level = np.zeros(max(nf, 1), np.int64)
+    top, bound = C.c_double(0), C.c_double(0)
+    code = L.spqr_amd_map_tree(sym._h, int(nparts), owner.ctypes.data, level.ctypes.data, C.byref(top), C.byref(bound))
+    if code != 0:
+        raise RuntimeError("spqr_amd_map_tree failed with code %d" % code)
+    return owner[:nf], level[:nf], float(top.value), float(bound.value)
+
+
+def factorize_multi(sym, A, ndev, devices=None, want_R=True):
+    """spqrgpu_amd_factorize_multi: one process, ndev parts of the assembly tree on the HIP devices
+    `devices` (default 0 .. ndev-1; parts may share a device).  Returns a result like spqr.factorize."""
+    import scipy.sparse as sp
+    L = spqr._bind()
+    L.spqrgpu_amd_factorize_multi.restype = C.c_int
+    L.spqrgpu_amd_factorize_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                              C.POINTER(C.POINTER(spqr.Numeric))]
+    csc = A if isinstance(A, _Csc) else _Csc(A)
+    devs = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+    out = C.POINTER(spqr.Numeric)()
+    code = L.spqrgpu_amd_factorize_multi(sym._h, csc.Ap.ctypes.data, csc.Ai.ctypes.data, csc.Ax.ctypes.data, int(ndev),
+                                         None if devs is None else devs.ctypes.data, C.byref(out))
+    if code != 0:
+        raise RuntimeError("spqrgpu_amd_factorize_multi failed with code %d" % code)
+    num = out.contents
+    n = int(sym.n)
+    res = spqr.NumericResult()
+    res.rank = int(num.sumfrank)
+    res.maxfrank = int(num.maxfrank)
+    res.gpuKernelTime = float(num.gpuKernelTime)
+    res.gpuNumKernelLaunches = int(num.gpuNumKernelLaunches)
+    res.numStagesRun = int(num.numStagesRun)
+    res.R = None
+    if want_R:
+        Rp = np.zeros(n + 1, dtype=np.int64)
+        L.spqr_amd_rconvert(sym._h, out, Rp.ctypes.data, None, None)
+        Ri = np.zeros(max(int(Rp[n]), 1), dtype=np.int64)
+        Rx = np.zeros(max(int(Rp[n]), 1), dtype=np.float64)
+        L.spqr_amd_rconvert(sym._h, out, Rp.ctypes.data, Ri.ctypes.data, Rx.ctypes.data)
+        res.R = sp.csc_matrix((Rx[:Rp[n]], Ri[:Rp[n]], Rp), shape=(max(res.rank, 0), n))
+    L.spqr_amd_numeric_free(out)
+    return res

@@ -69,3 +69,18 @@ def test_distributed_factorization_gloo(tmp_path, world, shape):
     A = problems.stacked_ls(dims)
     Rl = np.linalg.qr(A[:, z["Qfill"]].toarray(), mode="r")
     assert r_rel_diff(rownorm_sign(R), rownorm_sign(Rl)) <= 1e-12
+
+
+@pytest.mark.parametrize("shape,leaf,relax", [((24, 24), 4, 20), ((10, 10, 10), 3, -1), ((16, 16, 16), 4, -1), ((40, 9), 3, 0)])
+@pytest.mark.parametrize("parts", [1, 2, 3, 4, 8])
+def test_library_mapping_is_the_python_mapping(shape, leaf, relax, parts):
+    """spqr_amd_map_tree (what the one-process multi-GPU entry point uses) against multigpu.map_tree and
+    mapping_report: same owners, same levels, same bounds."""
+    from suitesparse_amd import multigpu, problems, spqr
+    A = problems.stacked_ls(shape)
+    sym = spqr.analyze(A, problems.nested_dissection(shape, leaf=leaf), relax=relax, gpuMemorySize=2**33)
+    owner, level = multigpu.map_tree(sym, parts)
+    rep = multigpu.mapping_report(sym, owner, level, parts)
+    o2, l2, top, bound = multigpu.map_tree_c(sym, parts)
+    assert np.array_equal(owner, o2) and np.array_equal(level, l2)
+    assert abs(top - rep["top_flops_share"]) <= 1e-12 and abs(bound - rep["speedup_bound"]) <= 1e-9 * bound

@@ -683,3 +683,21 @@ def test_h_kept_refuses_what_it_cannot_serve():
         spqr.KeptFactorization(rd, A, nrhs=1)
     with pytest.raises(RuntimeError):
         spqr.KeptFactorization(spqr.analyze(A, Q, gpuMemorySize=2**33), A, nrhs=1000)
+
+
+@pytest.mark.parametrize("shape,leaf,parts", [((20, 20), 3, 2), ((10, 10, 10), 3, 3), ((16, 16, 16), 4, 4), ((24, 24, 24), 4, 8)])
+def test_one_process_multi_device_entry_point_gives_the_single_device_r(shape, leaf, parts):
+    """spqrgpu_amd_factorize_multi (C, one process): the tree mapped onto `parts` devices by the library's
+    own spqr_amd_map_tree, one subset call per (part, level), blocks handed over on the device.  With one
+    GPU on the box every part names device 0 (the parts take turns on it); R must be the single-device
+    R bit for bit, with SPQR's own fronts."""
+    from suitesparse_amd import multigpu
+    A = problems.stacked_ls(shape)
+    sym = spqr.analyze(A, problems.nested_dissection(shape, leaf=leaf), relax=-1, gpuMemorySize=2**34)
+    res0 = spqr.factorize(sym, A)
+    owner, level, top, bound = multigpu.map_tree_c(sym, parts)
+    res = multigpu.factorize_multi(sym, A, parts, devices=[0] * parts)
+    assert res.rank == res0.rank == sym.n
+    assert (res.R != res0.R).nnz == 0
+    if parts > 1 and len(set(owner.tolist())) > 1:
+        assert res.numStagesRun >= len(set(zip(owner.tolist(), level.tolist())))
