@@ -155,6 +155,48 @@ def _r_size(sym, f):
     return rk * (rk + 1) // 2 + rk * (int(sym.Rp[f + 1] - sym.Rp[f]) - rk)
 
 
+import os as _os
+
+BAND = int(_os.environ.get("GPUQR_CUT_BAND", "2048"))      # rows per band of a contribution block on the wire
+
+
+def _c_shape(sym, f):
+    return int(sym.Cm[f]), int((sym.Rp[f + 1] - sym.Rp[f]) - (sym.Super[f + 1] - sym.Super[f]))
+
+
+def _band_sizes(sym, f):
+    """Elements of every band of front f's contribution block as it travels: rows [r0, r1) from column r0 on."""
+    cm, cn = _c_shape(sym, f)
+    return [(min(r0 + BAND, cm) - r0) * (cn - r0) for r0 in range(0, cm, BAND) if (cn - r0) > 0]
+
+
+def _bands_out(sym, f, t):
+    """The bands of a compact cm-by-cn block (1-D tensor) as contiguous tensors."""
+    cm, cn = _c_shape(sym, f)
+    if cm * cn == 0:
+        return []
+    t2 = t.reshape(cm, cn)
+    return [t2[r0:min(r0 + BAND, cm), r0:].contiguous().reshape(-1) for r0 in range(0, cm, BAND) if (cn - r0) > 0]
+
+
+def _bands_in(sym, f, pieces, device):
+    """The compact cm-by-cn block rebuilt from its bands (what lies left of a band's first column is never read)."""
+    import torch
+    cm, cn = _c_shape(sym, f)
+    out = torch.zeros(cm * cn, dtype=torch.float64, device=device)
+    if cm * cn == 0:
+        return out
+    o2 = out.reshape(cm, cn)
+    k = 0
+    for r0 in range(0, cm, BAND):
+        if cn - r0 <= 0:
+            continue
+        r1 = min(r0 + BAND, cm)
+        o2[r0:r1, r0:] = pieces[k].to(device).reshape(r1 - r0, cn - r0)
+        k += 1
+    return out
+
+
 class _Csc:
     """A's arrays in the types the C ABI wants, made once per factorization."""
 
@@ -305,7 +347,8 @@ def factorize_distributed(sym, A, factor_subset=None, gather_R=True, trace=None)
                 leaving[level[f]].append(f)
         static = dict(levels=nlev,
                       n_cut=sum(1 for L in leaving for f in L if owner[Parent[f]] != owner[f]),
-                      cut_bytes=8 * sum(_c_size(sym, f) for L in leaving for f in L if owner[Parent[f]] != owner[f]))
+                      cut_bytes=8 * sum(sum(_band_sizes(sym, f)) for L in leaving for f in L if owner[Parent[f]] != owner[f]),
+                      cut_bytes_rectangles=8 * sum(_c_size(sym, f) for L in leaving for f in L if owner[Parent[f]] != owner[f]))
         static.update(mapping_report(sym, owner, level, world))
         cache[world] = (owner, level, nlev, leaving, static)
     owner, level, nlev, leaving, static = cache[world]
@@ -334,6 +377,9 @@ def factorize_distributed(sym, A, factor_subset=None, gather_R=True, trace=None)
                 Rall.update(R)
             info["calls"].append(dict(level=L, fronts=int(mine.sum()), **st))
         # ---- the blocks that left level L, to whoever factorizes the parent ------------------------
+        # A contribution block is upper trapezoidal (entries left of the diagonal are never read,
+        # packAssemble.cu:47-55), so it travels as bands of BAND rows, each from its own first column on:
+        # a little over half of the cm-by-cn rectangle for a square block.
         ops, landing = [], []
         for f in leaving[L]:                            # increasing f on every rank: the pairs match up
             src, dst = int(owner[f]), int(owner[Parent[f]])
@@ -342,21 +388,22 @@ def factorize_distributed(sym, A, factor_subset=None, gather_R=True, trace=None)
             elif src == rank:
                 blk = Cout[f]
                 t = torch.from_numpy(np.ascontiguousarray(blk)) if host_blocks else blk
-                if t.numel() > 0:
-                    ops.append(dist.P2POp(dist.isend, t.to(wire), dst))
+                for piece in _bands_out(sym, f, t):
+                    ops.append(dist.P2POp(dist.isend, piece.to(wire), dst))
             elif dst == rank:
-                t = torch.empty(_c_size(sym, f), dtype=torch.float64, device=wire)
-                landing.append((f, t))
-                if t.numel() > 0:
-                    ops.append(dist.P2POp(dist.irecv, t, src))
+                pieces = [torch.empty(nel, dtype=torch.float64, device=wire) for nel in _band_sizes(sym, f)]
+                landing.append((f, pieces))
+                for piece in pieces:
+                    ops.append(dist.P2POp(dist.irecv, piece, src))
         trace("level %d: exchange, %d transfers" % (L, len(ops)))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
             if wire.type == "cuda":
                 torch.cuda.synchronize()
-        for f, t in landing:
-            held[f] = t.numpy() if host_blocks else t.to(cdev)
+        for f, pieces in landing:
+            t = _bands_in(sym, f, pieces, cdev if not host_blocks else torch.device("cpu"))
+            held[f] = t.numpy() if host_blocks else t
 
     trace("levels done")
     if not gather_R:

@@ -52,14 +52,16 @@ def test_mapping_of_a_chain_stays_on_one_rank():
     assert abs(rep["speedup_bound"] - 1.0) < 0.35
 
 
-@pytest.mark.parametrize("world,shape", [(2, "14x14"), (3, "7x7x7"), (4, "9x9x9")])
-def test_distributed_factorization_gloo(tmp_path, world, shape):
+@pytest.mark.parametrize("world,shape,band", [(2, "14x14", 2048), (3, "7x7x7", 5), (4, "9x9x9", 2048), (2, "9x9x9", 7)])
+def test_distributed_factorization_gloo(tmp_path, world, shape, band):
+    """(band: rows per band of a contribution block on the wire; the small values cut the test's blocks
+    into several upper-trapezoid bands, as the 2048 of production cuts a separator's block)"""
     out = str(tmp_path / "R.npz")
     port = 29500 + (os.getpid() % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "mgpu_worker.py"), "gloo", out, shape]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", GPUQR_CUT_BAND=str(band))
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     z = np.load(out)
