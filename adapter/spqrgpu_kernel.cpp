@@ -20,6 +20,7 @@
 
 #include "spqr.hpp"
 #include "spqrgpu_amd.h"
+#include <string.h>
 
 void spqrgpu_kernel (spqr_blob <double> *Blob)
 {
@@ -68,7 +69,30 @@ void spqrgpu_kernel (spqr_blob <double> *Blob)
 
     Long sumfrank = 0, maxfrank = 0, used = 0, flops = 0, launches = 0 ;
     double kernel_ms = 0 ;
-    int code = spqrgpu_amd_kernel (sym, Blob->Sx, Stack_head, (Long) (Stack_top - Stack_head),
+    int code ;
+    if (cc->numGPU > 1)
+    {
+        // Several devices (cholmod_common's numGPU, CHOLMOD/Include/cholmod_core.h:988; the reference's
+        // SPQR never reads it): the assembly tree is mapped onto devices 0 .. numGPU-1, one host thread
+        // per device, contribution blocks that change devices go by peer copies; all of R comes back in
+        // one numeric object, laid out like the stack, and is copied onto it.
+        spqr_amd_numeric *num = NULL ;
+        code = spqrgpu_amd_factorize_multi (sym, NULL, NULL, Blob->Sx, (int) cc->numGPU, NULL, &num) ;
+        if (code == 0)
+        {
+            if (num->rsize > (Long) (Stack_top - Stack_head)) code = 1 ;
+            else
+            {
+                if (num->rsize > 0) memcpy (Stack_head, num->Rstack, (size_t) num->rsize * sizeof (double)) ;
+                for (Long f = 0 ; f < nf ; f++) Rblock_offset [f] = num->Rblock [f] ;
+                for (Long k = 0 ; k < QRsym->n ; k++) if (num->Rdead [k]) QRnum->Rdead [k] = 1 ;
+                sumfrank = num->sumfrank ; maxfrank = num->maxfrank ; used = num->rsize ;
+                kernel_ms = num->gpuKernelTime ; flops = num->gpuFlops ; launches = num->gpuNumKernelLaunches ;
+            }
+            spqr_amd_numeric_free (num) ;
+        }
+    }
+    else code = spqrgpu_amd_kernel (sym, Blob->Sx, Stack_head, (Long) (Stack_top - Stack_head),
         Rblock_offset, QRnum->Rdead, &sumfrank, &maxfrank, &used, &kernel_ms, &flops, &launches) ;
     if (code == 0)
     {

@@ -421,6 +421,7 @@ def run_sparse(cx, kind, k, K, W, ordering="metis", profile=True):
     if cx.world > 1:
         out["multi"] = {"levels": last_info.get("levels"), "cut_blocks": last_info.get("n_cut"),
                         "cut_bytes": last_info.get("cut_bytes"),
+                        "cut_bytes_rectangles": last_info.get("cut_bytes_rectangles"),
                         "rank0_calls": last_info.get("calls")}
     return out
 
@@ -473,6 +474,9 @@ def main():
     cx.rank = int(os.environ.get("RANK", "0"))
     cx.world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if cx.world > 1:
+        sys.stderr.write("[bench] rank %d of %d started (pid %d)\n" % (cx.rank, cx.world, os.getpid()))
+        sys.stderr.flush()
     # BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (the ranks
     # then share devices); the driver's runs use RCCL, one GPU per rank
     cx.backend = os.environ.get("BENCH_BACKEND", "nccl")

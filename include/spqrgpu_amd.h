@@ -307,7 +307,10 @@ int64_t spqrgpu_amd_subset_csize (const spqr_amd_symbolic *sym, const char *mine
  * devices[k] = HIP device of part k (NULL: 0 .. ndev-1); parts may share a device (they then take turns
  * on it).  The result is one numeric object holding all of R on a pageable host stack, as
  * spqrgpu_amd_factorize leaves it; R is the single-device R bit for bit.  sym must have been analysed
- * without rank detection.  Return codes as spqrgpu_amd_factorize. */
+ * without rank detection.  Ap == NULL (here and in the two subset entry points): Ax holds the values of
+ * S = A(P,Q) in row form instead (SPQR's Blob->Sx, as spqrgpu_amd_kernel takes them), which is what an
+ * SPQR adapter passes for cc->numGPU > 1 (adapter/spqrgpu_kernel.cpp).  Return codes as
+ * spqrgpu_amd_factorize. */
 int spqr_amd_map_tree (const spqr_amd_symbolic *sym, int nparts, int64_t *owner, int64_t *level,
                        double *top_flops_share, double *speedup_bound);
 int spqrgpu_amd_factorize_multi (const spqr_amd_symbolic *sym, const int64_t *Ap, const int64_t *Ai,

@@ -2282,7 +2282,8 @@ extern "C" int spqrgpu_amd_factorize_subset
     const char *mine, const double *const *limbo_in, spqr_amd_numeric **num_out
 )
 {
-    if (!S || !Ap || !Ax || !mine || !num_out || (!Ai && S->anz > 0)) return 3 ;
+    // (Ap == NULL: Ax holds the values of S = A(P,Q) in row form, SPQR's Sx, as in spqrgpu_amd_kernel)
+    if (!S || !Ax || !mine || !num_out || (Ap && !Ai && S->anz > 0)) return 3 ;
     return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in, false, NULL, NULL, 0, NULL, NULL, num_out) ;
 }
 
@@ -2296,7 +2297,7 @@ extern "C" int spqrgpu_amd_factorize_subset_dev
     const char *mine, const double *const *limbo_in_dev, double *c_out_dev, spqr_amd_numeric **num_out
 )
 {
-    if (!S || !Ap || !Ax || !mine || !num_out || (!Ai && S->anz > 0)) return 3 ;
+    if (!S || !Ax || !mine || !num_out || (Ap && !Ai && S->anz > 0)) return 3 ;
     if (!c_out_dev && spqrgpu_amd_subset_csize (S, mine) > 0) return 3 ;
     return factorize_impl (S, Ap, Ai, Ax, mine, limbo_in_dev, true, c_out_dev, NULL, 0, NULL, NULL, num_out) ;
 }

@@ -221,7 +221,8 @@ extern "C" int spqrgpu_amd_factorize_multi
 )
 {
     if (num_out) *num_out = NULL ;
-    if (!S || !Ap || !Ax || !num_out || (!Ai && S->anz > 0) || ndev < 1 || ndev > 64) return 3 ;
+    // (Ap == NULL: Ax holds the values of S = A(P,Q) in row form, SPQR's Sx, which is all an SPQR adapter has)
+    if (!S || !Ax || !num_out || (Ap && !Ai && S->anz > 0) || ndev < 1 || ndev > 64) return 3 ;
     if (S->do_rank_detection || (Long) S->Qfill.size ( ) < S->n || (Long) S->PLinv.size ( ) < S->m) return 3 ;
     const Long nf = S->nf, n = S->n ;
     int ndevices_here = 0 ;

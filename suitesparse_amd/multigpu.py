@@ -482,19 +482,26 @@ def map_tree_c(sym, nparts):
     return owner[:nf], level[:nf], float(top.value), float(bound.value)
 
 
-def factorize_multi(sym, A, ndev, devices=None, want_R=True):
+def factorize_multi(sym, A, ndev, devices=None, want_R=True, Sx=None):
     """spqrgpu_amd_factorize_multi: one process, ndev parts of the assembly tree on the HIP devices
-    `devices` (default 0 .. ndev-1; parts may share a device).  Returns a result like spqr.factorize."""
+    `devices` (default 0 .. ndev-1; parts may share a device).  Returns a result like spqr.factorize.
+    With Sx (the values of S = A(P,Q) in row form, what an SPQR adapter holds) A is not looked at."""
     import scipy.sparse as sp
     L = spqr._bind()
     L.spqrgpu_amd_factorize_multi.restype = C.c_int
     L.spqrgpu_amd_factorize_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                               C.POINTER(C.POINTER(spqr.Numeric))]
-    csc = A if isinstance(A, _Csc) else _Csc(A)
     devs = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
     out = C.POINTER(spqr.Numeric)()
-    code = L.spqrgpu_amd_factorize_multi(sym._h, csc.Ap.ctypes.data, csc.Ai.ctypes.data, csc.Ax.ctypes.data, int(ndev),
-                                         None if devs is None else devs.ctypes.data, C.byref(out))
+    if Sx is not None:
+        Sx = np.ascontiguousarray(Sx, dtype=np.float64)
+        assert Sx.size == sym.anz
+        code = L.spqrgpu_amd_factorize_multi(sym._h, None, None, Sx.ctypes.data, int(ndev),
+                                             None if devs is None else devs.ctypes.data, C.byref(out))
+    else:
+        csc = A if isinstance(A, _Csc) else _Csc(A)
+        code = L.spqrgpu_amd_factorize_multi(sym._h, csc.Ap.ctypes.data, csc.Ai.ctypes.data, csc.Ax.ctypes.data, int(ndev),
+                                             None if devs is None else devs.ctypes.data, C.byref(out))
     if code != 0:
         raise RuntimeError("spqrgpu_amd_factorize_multi failed with code %d" % code)
     num = out.contents

@@ -2,6 +2,8 @@
 import ctypes as C
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -449,3 +451,20 @@ def test_host_code_under_address_and_ub_sanitizers():
     r = subprocess.run([os.path.join(d, "host_asan")], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1"))
     assert r.returncode == 0 and "all checks passed" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_bench_starts_its_own_ranks_and_fails_loudly_without_a_gpu():
+    """python bench.py --gpus 2 with no launcher around it starts two ranks itself (each says so before it
+    touches a device); on a machine without a GPU both then fail, and so does the command: there is no
+    CPU path to fall back to.  (With a GPU: tests/test_bench_gpu.py.)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this is the no-GPU behaviour")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "sparse3d:8",
+                        "--steps", "1", "--warmup", "1", "--extras", "none", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert "rank 0 of 2 started" in r.stderr and "rank 1 of 2 started" in r.stderr, r.stderr[-2000:]
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
