@@ -78,7 +78,7 @@ class Symbolic:
             setattr(self, name, arr)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _bind is not None:     # (_bind is None while the interpreter shuts down)
             _bind().spqr_amd_symbolic_free(self._h)
             self._h = None
 

@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    # the attributes child processes inherit, as they are before any test ran (for comparison with the
+    # report a failing child-process test writes)
+    try:
+        from tests.util import process_attrs
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "attrs_at_session_start.txt"), "w") as f:
+            f.write(process_attrs() + "\n")
+    except Exception:
+        pass
+
+
 # PyTorch ships its own copy of the HIP runtime.  A process that loads the engine (linked against
 # /opt/rocm's runtime) first and PyTorch second ends up with two runtimes, and the second one finds
 # no device.  Tests that use torch tensors as device buffers therefore need torch loaded first.
@@ -37,5 +49,10 @@ def _release_device_workspaces_between_modules():
         L.spqrgpu_amd_finalize()
         L.gpuqr_finalize()
         torch.cuda.empty_cache()
+        if os.environ.get("MGPU_AMD_LOG"):
+            # debugging aid: what this process still holds after each module
+            from tests.util import gpu_state_report
+            with open(os.path.join(ROOT, "gpurun_out", "state_by_module.txt"), "a") as f:
+                f.write("==== after %s\n%s\n" % (os.environ.get("PYTEST_CURRENT_TEST", "?"), gpu_state_report().split("parent attributes")[0]))
     except Exception:
         pass

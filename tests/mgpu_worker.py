@@ -53,6 +53,8 @@ def oracle_factor_subset(sym, A, mine, limbo):
 
 
 def main():
+    import faulthandler
+    faulthandler.enable()               # a rank that dies of a fatal signal says where (Python frames) on stderr
     import torch
     import torch.distributed as dist
     from suitesparse_amd import multigpu, problems, spqr
