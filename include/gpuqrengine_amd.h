@@ -237,7 +237,10 @@ int gpuqr_init (void);
  * workspace (or whose plan exceeds the host block) is refused with GPUQR_TOOLARGE before anything
  * is launched (gpuqr_noalloc_last_need() then tells the bytes it would take); fronts that ask for
  * the packed R hand-off (gpuRpack / cpuRpack) are refused with GPUQR_GPUERROR.  All calls on one GPU
- * share that GPU's workspace: calls that overlap on one GPU race, also with each other's results. */
+ * share that GPU's workspace: calls that overlap on one GPU race, also with each other's results.
+ * The static host block is one per process: calls from several threads (one per GPU) take turns on
+ * it, from planning to the last launch; calls of the other entry points on other threads are not
+ * affected. */
 #define GPUQR_TOOLARGE 3
 int gpuqr_factor_sparse_noalloc (gpuqr_front *fronts, int64_t numFronts, gpuqr_stats *stats);
 size_t gpuqr_noalloc_workspace_bytes (void);

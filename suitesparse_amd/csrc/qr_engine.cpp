@@ -27,6 +27,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <vector>
+#include <mutex>
 #include <thread>
 #include <atomic>
 #include <algorithm>
@@ -70,7 +71,11 @@ extern "C" void gpuqr_set_allocator (void *(*m) (size_t), void *(*c) (size_t, si
 #define GPUQR_HOST_ARENA_BYTES ((size_t) 128 << 20)
 static unsigned char g_host_arena [GPUQR_HOST_ARENA_BYTES] __attribute__ ((aligned (64))) ;
 static size_t g_host_arena_pos = 0 ;
-static bool g_host_arena_on = false ;
+// The switch belongs to the calling thread: vectors that other threads allocate meanwhile (a call on
+// another device) keep coming from the heap.  The block itself is one per process, so the calls that
+// use it take turns (g_host_arena_turn).
+static thread_local bool g_host_arena_on = false ;
+static std::mutex g_host_arena_turn ;
 
 static inline bool in_host_arena (const void *p)
 {
@@ -79,7 +84,8 @@ static inline bool in_host_arena (const void *p)
 
 struct HostArenaScope
 {
-    HostArenaScope ( ) { g_host_arena_pos = 0 ; g_host_arena_on = true ; }
+    std::lock_guard<std::mutex> turn ;
+    HostArenaScope ( ) : turn (g_host_arena_turn) { g_host_arena_pos = 0 ; g_host_arena_on = true ; }
     ~HostArenaScope ( ) { g_host_arena_on = false ; }
 } ;
 

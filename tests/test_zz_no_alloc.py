@@ -146,6 +146,57 @@ def test_noalloc_matches_the_allocating_entry_point_twice_then_refuses_too_much(
     ref_m, got_m = _both(L, make_m, torch.zeros(nwords_m, dtype=torch.float64, device=dev))
     assert np.array_equal(ref_m, ref) and np.array_equal(got_m, ref)
 
+    # what the entry point is named for: with the device set up (gpuqr_init, and the calls above), a
+    # call allocates nothing: no host allocation through the library's hooks, no device memory
+    MALLOC = C.CFUNCTYPE(C.c_void_p, C.c_size_t)
+    CALLOC = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_size_t)
+    FREE = C.CFUNCTYPE(None, C.c_void_p)
+    libc = C.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes = C.c_void_p, [C.c_size_t]
+    libc.calloc.restype, libc.calloc.argtypes = C.c_void_p, [C.c_size_t, C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    calls = {"malloc": 0, "calloc": 0}
+
+    def counting_malloc(sz):
+        calls["malloc"] += 1
+        return libc.malloc(sz)
+
+    def counting_calloc(a, b):
+        calls["calloc"] += 1
+        return libc.calloc(a, b)
+
+    cbs = (MALLOC(counting_malloc), CALLOC(counting_calloc), FREE(lambda p: libc.free(p)))
+    L.gpuqr_set_allocator.argtypes = [MALLOC, CALLOC, FREE]
+    buf = torch.zeros(nwords_m, dtype=torch.float64, device=dev)
+    keep_n = []
+    arr = engine._pack(make_m(buf), keep_n)
+    st = _lib.Stats()
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info()
+    try:
+        L.gpuqr_set_allocator(*cbs)
+        code = L.gpuqr_factor_sparse_noalloc(arr, arr._length_, C.byref(st))
+    finally:
+        L.gpuqr_set_allocator(MALLOC(0), CALLOC(0), FREE(0))
+    torch.cuda.synchronize()
+    free_after, _ = torch.cuda.mem_get_info()
+    assert code == _lib.GPUQR_SUCCESS
+    assert calls == {"malloc": 0, "calloc": 0}, calls
+    assert free_after == free_before
+    assert np.array_equal(buf.cpu().numpy(), ref)
+    # (the allocating entry point under the same hooks, on a batch it has not seen, does call them: the
+    # hooks are live)
+    make_a, flat_a = _dense_batch([rng.standard_normal((130, 50)), rng.standard_normal((77, 33))])
+    keep_a = []
+    arr2 = engine._pack(make_a(flat_a.clone()), keep_a)
+    try:
+        L.gpuqr_set_allocator(*cbs)
+        assert L.gpuqr_factor_sparse(0, arr2, arr2._length_, None, None, None, C.byref(st)) == _lib.GPUQR_SUCCESS
+    finally:
+        L.gpuqr_set_allocator(MALLOC(0), CALLOC(0), FREE(0))
+    torch.cuda.synchronize()
+    assert calls["malloc"] + calls["calloc"] > 0
+
     # beyond the fixed workspace: refused before anything is launched, the front is untouched
     m, n = 16384, 4096
     big = torch.ones(m * n, dtype=torch.float64, device=dev)
