@@ -513,6 +513,50 @@ struct PinnedStackCache
 } ;
 static PinnedStackCache g_pinned_stack ;
 
+// The same for pageable stacks of 1 GiB and more (what a stack beyond the page-locking limit is): the
+// 70 GB of a 128^3 grid cost about a second per factorization in page faults on first touch and in
+// giving the pages back.  These stacks come from malloc directly, not through the allocator hooks, so
+// that one kept across a change of hooks is freed by what allocated it.
+struct PageableStackCache
+{
+    static const size_t min_bytes = (size_t) 1 << 30 ;
+    std::mutex lock ;
+    void *kept = NULL ; size_t kept_bytes = 0 ;
+    std::vector<std::pair<void *, size_t> > lent ;
+    void *get (size_t bytes)
+    {
+        std::lock_guard<std::mutex> g (lock) ;
+        void *p = NULL ; size_t have = 0 ;
+        if (kept && kept_bytes >= bytes && kept_bytes <= 2 * bytes + ((size_t) 64 << 20)) { p = kept ; have = kept_bytes ; kept = NULL ; kept_bytes = 0 ; }
+        else { p = malloc (bytes) ; have = bytes ; }
+        if (!p) return NULL ;
+        try { lent.push_back (std::make_pair (p, have)) ; } catch (...) { free (p) ; return NULL ; }
+        return p ;
+    }
+    bool give (void *p)                 // false: not one of these stacks
+    {
+        void *drop = NULL ;
+        {
+            std::lock_guard<std::mutex> g (lock) ;
+            size_t i = 0 ;
+            while (i < lent.size ( ) && lent [i].first != p) i++ ;
+            if (i == lent.size ( )) return false ;
+            drop = kept ;
+            kept = p ; kept_bytes = lent [i].second ;
+            lent.erase (lent.begin ( ) + i) ;
+        }
+        if (drop) free (drop) ;
+        return true ;
+    }
+    void clear ( )
+    {
+        void *drop = NULL ;
+        { std::lock_guard<std::mutex> g (lock) ; drop = kept ; kept = NULL ; kept_bytes = 0 ; }
+        if (drop) free (drop) ;
+    }
+} ;
+static PageableStackCache g_pageable_stack ;
+
 // The largest R stack this driver asks the system to page-lock (GPUQR_PIN_LIMIT_GIB, default 48); a
 // larger one is pageable and filled through bounce buffers.  Systems refuse pinned memory beyond some
 // total (64 GB on the machine this was developed on), and an allocation just above that total does not
@@ -537,7 +581,7 @@ extern "C" void spqr_amd_numeric_free (spqr_amd_numeric *num)
     if (num->Rstack && !num->RstackBorrowed)
     {
         if (num->RstackPinned) g_pinned_stack.give (num->Rstack, (size_t) std::max ((Long) 1, num->rsize) * sizeof (double)) ;
-        else host_free (num->Rstack) ;
+        else if (!g_pageable_stack.give (num->Rstack)) host_free (num->Rstack) ;
     }
     host_free (num->Rblock) ; host_free (num->Rdead) ; host_free (num->Cstack) ; host_free (num->Cblock) ;
     host_free (num) ;
@@ -622,6 +666,7 @@ extern "C" void spqrgpu_amd_finalize (void)
         W.hBounce [0].release ( ) ; W.hBounce [1].release ( ) ;
     }
     g_pinned_stack.clear ( ) ;
+    g_pageable_stack.clear ( ) ;
     g_ws_gen++ ;
     if (cur >= 0) (void) hipSetDevice (cur) ;
 }
@@ -840,7 +885,8 @@ static int factorize_impl
         {
             (void) hipGetLastError ( ) ;
             num->RstackPinned = 0 ;
-            num->Rstack = (double *) host_malloc ((size_t) std::max ((Long) 1, rtotal) * sizeof (double)) ;
+            const size_t rbytes = (size_t) std::max ((Long) 1, rtotal) * sizeof (double) ;
+            num->Rstack = (double *) (rbytes >= PageableStackCache::min_bytes ? g_pageable_stack.get (rbytes) : host_malloc (rbytes)) ;
             if (!num->Rstack) { code = 1 ; goto done ; }
         }
         num->Rblock = (Long *) host_malloc ((size_t) std::max ((Long) 1, nf) * sizeof (Long)) ;
