@@ -15,7 +15,7 @@ from suitesparse_amd import multigpu, problems, spqr
 MEM = int(float(os.environ.get("BENCH_DEVICE_GIB", "200")) * 2**30)
 
 
-def run(shape, mode, reps=2):
+def run(shape, mode, reps=int(os.environ.get("PROBE_REPS", "2"))):
     A = problems.stacked_ls(shape)
     t0 = time.perf_counter()
     if mode == "metis":

@@ -197,7 +197,25 @@ struct SchedTask
     int32_t is_rhs ;    // update task whose columns are the front's right-hand-side block (kept for Q'B replays)
     double  flops ;     // algorithmic flops of this task
     double  bytes ;     // algorithmic (minimum) bytes it moves to and from memory
+#ifdef GPUQR_EXPERIMENT_DRY
+    int32_t dry ;       // timing experiment only (see below): the update does its arithmetic without touching the block
+#endif
 } ;
+
+#ifdef GPUQR_EXPERIMENT_DRY
+// Timing experiment, compiled into a library of its own (make exp), never into the product: what would
+// a step take if the first-level updates of every second panel cost their matrix arithmetic alone,
+// i.e. if two consecutive 32-wide panels shared one trip of the trailing block through the registers
+// (the 64-reflector update)?  With GPUQR_EXPERIMENT_DRY=1 those update tasks are marked; the kernel then
+// works on zeros instead of loading the block and stores nothing.  The results of such a run are
+// meaningless; its launch times are those of the same schedule with that traffic removed.
+static bool experiment_dry (void)
+{
+    static int on = -1 ;
+    if (on < 0) { const char *e = getenv ("GPUQR_EXPERIMENT_DRY") ; on = (e && *e && *e != '0') ? 1 : 0 ; }
+    return on == 1 ;
+}
+#endif
 
 // -----------------------------------------------------------------------------
 // optional per-kernel profile (HIP events around every launch)
@@ -483,6 +501,9 @@ static void plan_front
                         for (int c = 0 ; c < QR_NCLASS ; c++) st.dep [c] = dep [c] ;
                         st.vt = fr.vt ;
                         st.nblk = (int32_t) nblk ;
+#ifdef GPUQR_EXPERIMENT_DRY
+                        st.dry = (experiment_dry ( ) && lv == 0 && (p & 1) && !critical) ? 1 : 0 ;
+#endif
                         st.flops = (double) flops_apply (fr.K, w, ce - cb) ;
                         // A read + written once; V (K x 32) and the VT tile read once per workgroup
                         st.bytes = 16.0 * fr.K * (double) (ce - cb) + (double) nblk * (8.0 * fr.K * w + 8.0 * QR_VT_DOUBLES) ;
@@ -1723,6 +1744,9 @@ static int stage_tasks (Schedule &sc, double *d_vt, QrTask *h_tasks, QrRef *h_re
                 if (!ok || acc != pt.K) bad.store (1) ;
             }
             h_tasks [i] = st.t ;
+#ifdef GPUQR_EXPERIMENT_DRY
+            if (st.t.type == QR_TASK_APPLY && st.dry) h_tasks [i].u.panel.w |= 64 ;
+#endif
             int64_t q = at [(size_t) i] ;
             for (int32_t b = 0 ; b < st.nblk ; b++) { h_refs [q].task = (int32_t) i ; h_refs [q].blk = b ; q++ ; }
         }

@@ -432,6 +432,11 @@ __device__ __forceinline__ void factorize_panel (const QrPanelTask &t, char *sme
 #ifndef MFMA64
 #define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64 ((a), (b), (c), 0, 0, 0)
 #endif
+#ifdef GPUQR_EXPERIMENT_DRY
+// timing experiment (its own library, make exp): a marked update task works on zeros and stores nothing
+#define SLAB_LOAD(p) (dry_ ? d2 {0.0, 0.0} : *(p))
+#define SLAB_STORE(v, p) do { if (!dry_) *(p) = (v) ; } while (0)
+#endif
 #ifndef SLAB_LOAD
 #define SLAB_LOAD(p) (*(p))
 #define SLAB_STORE(v, p) (*(p) = (v))
@@ -445,7 +450,12 @@ __device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk
     int *rowmap = reinterpret_cast<int *>(smem + (size_t) (MT*16 + 32)*VS_LD*8) ;            // [MT*16]
 
     const int tid = threadIdx.x ;
+#ifdef GPUQR_EXPERIMENT_DRY
+    const int K = t.K, w = t.w & 63, ld = t.ld ;
+    const bool dry_ = (t.w & 64) != 0 ;
+#else
     const int K = t.K, w = t.w, ld = t.ld ;
+#endif
     const int kmax = (K < w) ? K : w ;
     gdouble *F = (gdouble *) t.F ;
     gcdouble *VT = (gcdouble *) t.VT ;
@@ -597,7 +607,11 @@ __device__ __forceinline__ void apply_block (const QrPanelTask &t, const int blk
                 if (r < K)
                 {
                     if (v1)      SLAB_STORE (o, (gd2 *) (rowp + col)) ;
+#ifdef GPUQR_EXPERIMENT_DRY
+                    else if (v0 && !dry_) rowp [col] = o.x ;
+#else
                     else if (v0) rowp [col] = o.x ;
+#endif
                 }
                 A [mt][h] = SLAB_LOAD ((gd2 *) (rowp + nlcol)) ;
             }
