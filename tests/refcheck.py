@@ -25,6 +25,42 @@ def ash219_standin():
     return sp.csc_matrix((np.ones(438), (rows, cols)), shape=(219, 85))
 
 
+def read_harwell_boeing(path):
+    """A real assembled Harwell-Boeing file (RUA) as CSC: header of four lines, then column pointers,
+    row indices and values in the fixed-width Fortran formats the header names (scipy's reader does not
+    take formats like (1P3D24.15))."""
+    import re
+
+    def width(fmt):
+        # (16I5) -> 5; (1P3D24.15) -> 24; (4D20.12) -> 20
+        m = re.search(r"(\d+)\s*[IiDdEeFfGg]\s*(\d+)", fmt.replace("1P", "").replace("1p", "").replace(",", ""))
+        return int(m.group(2))
+
+    with open(path) as f:
+        lines = f.read().split("\n")
+    counts = [int(x) for x in lines[1].split()]
+    ptrcrd, indcrd, valcrd = counts[1], counts[2], counts[3]
+    mxtype = lines[2][:3].upper()
+    nrow, ncol, nnz = (int(x) for x in lines[2][3:].split()[:3])
+    assert mxtype == "RUA", mxtype
+    fmts = re.findall(r"\([^)]*\)", lines[3])
+
+    def fields(first, ncards, w, count):
+        out = []
+        for ln in lines[first:first + ncards]:
+            out += [ln[i:i + w] for i in range(0, len(ln.rstrip()), w)]
+        return [x for x in out if x.strip()][:count]
+
+    at = 4
+    ptr = np.array([int(x) for x in fields(at, ptrcrd, width(fmts[0]), ncol + 1)]) - 1
+    at += ptrcrd
+    ind = np.array([int(x) for x in fields(at, indcrd, width(fmts[1]), nnz)]) - 1
+    at += indcrd
+    val = np.array([float(x.replace("D", "E").replace("d", "e")) for x in fields(at, valcrd, width(fmts[2]), nnz)])
+    assert len(ptr) == ncol + 1 and len(ind) == nnz and len(val) == nnz and ptr[-1] == nnz
+    return sp.csc_matrix((val, ind, ptr), shape=(nrow, ncol))
+
+
 def matrix(name):
     kind, arg = name.split(":")
     if kind == "grid":
@@ -34,6 +70,14 @@ def matrix(name):
         return problems.rank_deficient_ls(k, nd, nn)[0]
     if kind == "ash219":
         return ash219_standin()
+    if kind == "hb":
+        # a Harwell-Boeing file of the reference tree, read where it lies (never copied); the test is
+        # skipped on a machine without the tree
+        import os
+        path = os.path.join("/root/reference/UMFPACK/Demo/HB", arg)
+        if not os.path.exists(path):
+            pytest.skip("the reference tree is not on this machine")
+        return read_harwell_boeing(path)
     if kind == "rand":
         m, n, seed = (int(x) for x in arg.split("x"))
         A = sp.random(m, n, density=3.0 / n, random_state=seed, format="csc")

@@ -92,3 +92,26 @@ def test_oracle_rank_rule_equals_the_reference(mname, ordering):
     rc.check_numeric(R, rank, Rdead, r, tol=1e-11)
     # the norm of what the dead columns left behind is itself at rounding level (far below tol)
     assert abs(enorm - r.norm_E_fro) <= 1e-3 * r.tol_used and enorm <= r.tol_used * np.sqrt(max(int(Rdead.sum()), 1))
+
+
+HB_CASES = [(f, o) for f in ("west0067.rua", "arc130.rua", "fs_183_6.rua") for o in (rc.ORD_FIXED, rc.ORD_COLAMD, rc.ORD_AMD)]
+
+
+@pytest.mark.parametrize("fname,ordering", HB_CASES, ids=["%s-o%d" % c for c in HB_CASES])
+@pytest.mark.parametrize("with_tol", [False, True], ids=["notol", "tol"])
+def test_bundled_unsymmetric_matrices_against_the_reference(fname, ordering, with_tol):
+    """The real unsymmetric matrices the reference tree holds (UMFPACK/Demo/HB, read in place): symbolic
+    arrays bit for bit, then the oracle's R, rank and dead columns against the reference's, without a
+    tolerance and at SPQR_DEFAULT_TOL.  (Cases in which the reference removes column singletons first are
+    skipped: the GPU path only ever sees the matrix without them, spqr_1factor.cpp:236-246.)"""
+    A = rc.matrix("hb:" + fname)
+    r = rc.reference(A, ordering, rc.DEFAULT_TOL if with_tol else rc.NO_TOL)
+    sym = spqr.analyze(A, r.Q, relax=-1, gpuMemorySize=2**34, rank_detection=with_tol)
+    rc.check_symbolic(sym, r)
+    if with_tol:
+        R, Rdead, rank, _, enorm = oracle.multifrontal_tol(sym, spqr.s_values(sym, A), r.tol_used)
+        rc.check_numeric(R, rank, Rdead, r, tol=1e-10)
+    else:
+        R = _oracle_r(sym, A)
+        rank = int(sum(min(int(sym.Fm[f]), int(sym.Super[f + 1] - sym.Super[f])) for f in range(sym.nf)))
+        rc.check_numeric(R[:rank], rank, np.zeros(sym.n, np.int8), r, tol=1e-10)
