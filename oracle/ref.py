@@ -17,7 +17,7 @@ ORDERING_FIXED, ORDERING_NATURAL, ORDERING_COLAMD, ORDERING_AMD, ORDERING_METIS,
 NO_TOL, DEFAULT_TOL = -1.0, -2.0
 
 _INT_ARRAYS = ("Super", "Rp", "Rj", "Parent", "Childp", "Child", "Post", "Fm", "Cm", "Sp", "Sj", "Sleft",
-               "PLinv", "Qfill", "Q1fill")
+               "PLinv", "Qfill", "Q1fill", "P1inv")
 
 
 def available():

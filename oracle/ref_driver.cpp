@@ -143,6 +143,7 @@ Long ref_get (void *hv, const char *name, Long *out)
     else if (!strcmp (name, "PLinv"))  { src = s->PLinv ;  len = m ; }
     else if (!strcmp (name, "Qfill"))  { src = s->Qfill ;  len = s->Qfill ? n : 0 ; }
     else if (!strcmp (name, "Q1fill")) { src = h->QR->Q1fill ; len = h->QR->Q1fill ? h->QR->nacols : 0 ; }
+    else if (!strcmp (name, "P1inv"))  { src = h->QR->P1inv ;  len = h->QR->P1inv ? h->QR->narows : 0 ; }
     else if (!strcmp (name, "E"))      { src = h->E ;      len = h->E ? n : 0 ; }
     if (len > 0 && out && src) memcpy (out, src, len * sizeof (Long)) ;
     return (len) ;

@@ -94,6 +94,43 @@ def reference(A, ordering, tol=NO_TOL, want_R=True):
     return r
 
 
+def reference_pruned(A, ordering, tol=NO_TOL, want_R=True):
+    """As reference(), for matrices from which SPQR removes column singletons first (spqr_1colamd): returns
+    (Y, r) where Y is the matrix the multifrontal part factorizes, built from the reference's singleton
+    permutations as spqr_1factor.cpp:526-552 builds it: Y(P1inv[i] - n1rows, k - n1cols) = A(i, Q1fill[k])
+    for the rows and columns behind the singletons.  Its columns are already in the order to factorize
+    them in (r.Q is the identity); r.Q1fill keeps the whole permutation."""
+    r = ref.spqr(A, ordering=ordering, tol=tol, symbolic=True, want_R=want_R)
+    n = A.shape[1]
+    if r.n1cols == 0:
+        r.Q = r.Q1fill if r.Q1fill.size else np.arange(n, dtype=np.int64)
+        return sp.csc_matrix(A), r
+    P1 = np.argsort(r.P1inv)                    # row P1[k] of A is row k after the singleton permutation
+    Y = sp.csc_matrix(sp.csc_matrix(A)[P1[r.n1rows:], :][:, r.Q1fill[r.n1cols:]])
+    Y.sort_indices()
+    r.Q = np.arange(n - r.n1cols, dtype=np.int64)
+    return Y, r
+
+
+def check_numeric_pruned(R, rank, Rdead, r, tol=1e-12):
+    """check_numeric when the reference took singletons out first: R here is the factor of Y, the
+    reference's R is [R11 R12; 0 R22] with n1rows singleton rows on top; R22 is what must agree, the rank is
+    n1rows more, and E lists the singleton columns first."""
+    n2 = r.n - r.n1cols
+    assert int(rank) + r.n1rows == r.rank == r.rank_R, (rank, r.n1rows, r.rank, r.rank_R)
+    assert np.array_equal(np.asarray(Rdead[:n2]).astype(np.int8), r.Rdead[:n2])
+    order = squeeze_order(r.Rdead, n2)
+    q1 = r.Q1fill if r.Q1fill.size else np.arange(r.n, dtype=np.int64)
+    assert np.array_equal(np.concatenate([q1[:r.n1cols], q1[r.n1cols:][order]]), r.E)
+    Ra = abs(sp.csc_matrix(R))[:, order].tocsc()[:rank]
+    Rg = abs(sp.csc_matrix(r.R))[r.n1rows:r.n1rows + rank, r.n1cols:]
+    scale = float(abs(sp.csc_matrix(r.R)).max())
+    diff = abs(Ra - Rg)
+    err = float(diff.max()) / scale if diff.nnz else 0.0
+    assert err <= tol, err
+    return err
+
+
 def check_symbolic(sym, r):
     """Every symbolic array equal to the reference's QRsym, entry for entry."""
     assert int(sym.nf) == r.nf, ("nf", sym.nf, r.nf)

@@ -33,8 +33,7 @@ def test_symbolic_arrays_equal_the_reference(mname, ordering, rank_detection):
     PLinv, Qfill, Fm, Cm and the flop count of spqr_amd_analyze in its SPQR-compatible mode against
     QRsym of the reference's spqr_1factor (SPQR/Source/spqr_1factor.cpp:624-641 -> spqr_analyze.cpp),
     for the column order the reference itself chose with each of its ordering methods."""
-    A = rc.matrix(mname)
-    r = rc.reference(A, ordering, rc.DEFAULT_TOL if rank_detection else rc.NO_TOL, want_R=False)
+    A, r = rc.reference_pruned(rc.matrix(mname), ordering, rc.DEFAULT_TOL if rank_detection else rc.NO_TOL, want_R=False)
     sym = spqr.analyze(A, r.Q, relax=-1, gpuMemorySize=2**34, rank_detection=rank_detection)
     rc.check_symbolic(sym, r)
 
@@ -68,12 +67,11 @@ def test_oracle_r_equals_the_reference(mname, ordering):
     """The oracle's multifrontal factorization (the device's Householder convention, restated on the
     CPU) on the reference's own fronts gives the reference's R = Q'AE: |R| to 1e-12 of its largest
     entry, same rank."""
-    A = rc.matrix(mname)
-    r = rc.reference(A, ordering)
+    A, r = rc.reference_pruned(rc.matrix(mname), ordering)
     sym = spqr.analyze(A, r.Q, relax=-1, gpuMemorySize=2**34)
     R = _oracle_r(sym, A)
     rank = int(sum(min(int(sym.Fm[f]), int(sym.Super[f + 1] - sym.Super[f])) for f in range(sym.nf)))
-    rc.check_numeric(R[:rank], rank, np.zeros(sym.n, np.int8), r)
+    rc.check_numeric_pruned(R[:rank], rank, np.zeros(sym.n, np.int8), r)
 
 
 TOL_CASES = [("rankdef:24x6x6", rc.ORD_COLAMD), ("rankdef:24x6x6", rc.ORD_METIS), ("rankdef:64x16x16", rc.ORD_METIS),
@@ -84,12 +82,12 @@ TOL_CASES = [("rankdef:24x6x6", rc.ORD_COLAMD), ("rankdef:24x6x6", rc.ORD_METIS)
 def test_oracle_rank_rule_equals_the_reference(mname, ordering):
     """The oracle's restatement of the dead-column rule (spqr_front.cpp:424-479) against the reference
     run with SPQR_DEFAULT_TOL: rank, Rdead, the squeezed R and norm_E_fro."""
-    A = rc.matrix(mname)
-    r = rc.reference(A, ordering, rc.DEFAULT_TOL)
-    assert abs(spqr.default_tol(A) - r.tol_used) <= 1e-15 * r.tol_used
+    A0 = rc.matrix(mname)
+    A, r = rc.reference_pruned(A0, ordering, rc.DEFAULT_TOL)
+    assert abs(spqr.default_tol(A0) - r.tol_used) <= 1e-15 * r.tol_used     # (the tolerance comes from the whole matrix)
     sym = spqr.analyze(A, r.Q, relax=-1, gpuMemorySize=2**34, rank_detection=True)
     R, Rdead, rank, _, enorm = oracle.multifrontal_tol(sym, spqr.s_values(sym, A), r.tol_used)
-    rc.check_numeric(R, rank, Rdead, r, tol=1e-11)
+    rc.check_numeric_pruned(R, rank, Rdead, r, tol=1e-11)
     # the norm of what the dead columns left behind is itself at rounding level (far below tol)
     assert abs(enorm - r.norm_E_fro) <= 1e-3 * r.tol_used and enorm <= r.tol_used * np.sqrt(max(int(Rdead.sum()), 1))
 
@@ -102,16 +100,17 @@ HB_CASES = [(f, o) for f in ("west0067.rua", "arc130.rua", "fs_183_6.rua") for o
 def test_bundled_unsymmetric_matrices_against_the_reference(fname, ordering, with_tol):
     """The real unsymmetric matrices the reference tree holds (UMFPACK/Demo/HB, read in place): symbolic
     arrays bit for bit, then the oracle's R, rank and dead columns against the reference's, without a
-    tolerance and at SPQR_DEFAULT_TOL.  (Cases in which the reference removes column singletons first are
-    skipped: the GPU path only ever sees the matrix without them, spqr_1factor.cpp:236-246.)"""
+    tolerance and at SPQR_DEFAULT_TOL.  Where the reference removes column singletons first, the
+    multifrontal part sees the pruned matrix (spqr_1factor.cpp:526-552), and so does this path: the
+    matrix is pruned with the reference's own singleton permutations, and R22 of its [R11 R12; 0 R22] is
+    what is compared."""
     A = rc.matrix("hb:" + fname)
-    r = rc.reference(A, ordering, rc.DEFAULT_TOL if with_tol else rc.NO_TOL)
-    sym = spqr.analyze(A, r.Q, relax=-1, gpuMemorySize=2**34, rank_detection=with_tol)
+    Y, r = rc.reference_pruned(A, ordering, rc.DEFAULT_TOL if with_tol else rc.NO_TOL)
+    sym = spqr.analyze(Y, r.Q, relax=-1, gpuMemorySize=2**34, rank_detection=with_tol)
     rc.check_symbolic(sym, r)
     if with_tol:
-        R, Rdead, rank, _, enorm = oracle.multifrontal_tol(sym, spqr.s_values(sym, A), r.tol_used)
-        rc.check_numeric(R, rank, Rdead, r, tol=1e-10)
+        R, Rdead, rank, _, enorm = oracle.multifrontal_tol(sym, spqr.s_values(sym, Y), r.tol_used)
     else:
-        R = _oracle_r(sym, A)
         rank = int(sum(min(int(sym.Fm[f]), int(sym.Super[f + 1] - sym.Super[f])) for f in range(sym.nf)))
-        rc.check_numeric(R[:rank], rank, np.zeros(sym.n, np.int8), r, tol=1e-10)
+        R, Rdead = _oracle_r(sym, Y)[:rank], np.zeros(sym.n, np.int8)
+    rc.check_numeric_pruned(R, rank, Rdead, r, tol=1e-10)

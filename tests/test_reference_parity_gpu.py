@@ -27,12 +27,11 @@ def test_hip_path_reproduces_the_reference(mname, ordering, mem):
     """configs 1, 3 and 4 of the baseline at test sizes, one stage and several (mem = the declared
     device memory; 0 = every front its own stage, the reference's own staging test,
     SPQR/Tcov/qrtest.cpp:2660-2684)."""
-    A = rc.matrix(mname)
-    r = rc.reference(A, ordering)
+    A, r = rc.reference_pruned(rc.matrix(mname), ordering)
     sym = spqr.analyze(A, r.Q, relax=-1, gpuMemorySize=mem)
     rc.check_symbolic(sym, r)
     res = spqr.factorize(sym, A)
-    err = rc.check_numeric(res.R, res.rank, res.Rdead, r)
+    err = rc.check_numeric_pruned(res.R, res.rank, res.Rdead, r)
     assert err <= 1e-12
 
 
@@ -46,12 +45,11 @@ def test_rank_detection_on_the_device_equals_the_reference(mname, ordering):
     """config 5: duplicated and nearly dependent columns at SPQR_DEFAULT_TOL; the reference's CPU path
     (spqr_front.cpp:424-479, blocked, fchunk 32) decides rank and dead columns, the device must decide
     the same and deliver the same squeezed R."""
-    A = rc.matrix(mname)
-    r = rc.reference(A, ordering, rc.DEFAULT_TOL)
+    A, r = rc.reference_pruned(rc.matrix(mname), ordering, rc.DEFAULT_TOL)
     sym = spqr.analyze(A, r.Q, relax=-1, gpuMemorySize=2**34, rank_detection=True)
     rc.check_symbolic(sym, r)
     res = spqr.factorize(sym, A, tol=r.tol_used)
-    rc.check_numeric(res.R, res.rank, res.Rdead, r, tol=1e-11)
+    rc.check_numeric_pruned(res.R, res.rank, res.Rdead, r, tol=1e-11)
     assert abs(res.norm_E_fro - r.norm_E_fro) <= 1e-3 * r.tol_used
 
 
@@ -64,7 +62,7 @@ def test_config3_at_full_size_equals_the_reference():
     sym = spqr.analyze(A, r.Q, relax=-1, gpuMemorySize=200 * 2**30)
     rc.check_symbolic(sym, r)
     res = spqr.factorize(sym, A)
-    err = rc.check_numeric(res.R, res.rank, res.Rdead, r)
+    err = rc.check_numeric_pruned(res.R, res.rank, res.Rdead, r)
     print("config 3 at full size: rank %d, nnz(R) %d, max | |R| - |R_ref| | / max|R_ref| = %.2e" % (res.rank, res.R.nnz, err))
 
 
@@ -76,5 +74,5 @@ def test_3d_48_equals_the_reference():
     sym = spqr.analyze(A, r.Q, relax=-1, gpuMemorySize=200 * 2**30)
     rc.check_symbolic(sym, r)
     res = spqr.factorize(sym, A)
-    err = rc.check_numeric(res.R, res.rank, res.Rdead, r)
+    err = rc.check_numeric_pruned(res.R, res.rank, res.Rdead, r)
     print("3D 48^3: rank %d, nnz(R) %d, max rel diff %.2e" % (res.rank, res.R.nnz, err))
