@@ -195,6 +195,35 @@ def pmc_traffic(kernel, workload_tag):
     return None, None
 
 
+def isolated_assembly():
+    """The assembly kernel alone (one launch on a 16,384^2 block, inputs resident), from the committed output
+    of scripts/ubench/assemble_bench.hip: the figure to hold against the chip's peak; what a step's
+    own launches reach beside the update kernel is `achieved`."""
+    import re
+    path = os.path.join(ROOT, "profiles", "r03_ubench_assemble.txt")
+    try:
+        out = {}
+        for ln in open(path):
+            if ln.startswith("device-to-device copy") and "device_copy_GBps" not in out:
+                out["device_copy_GBps"] = float(re.search(r"([\d.]+) TB/s", ln).group(1)) * 1e3
+            m = re.search(r"([\d.]+) TB/s = ([\d.]+) of 8 TB/s", ln)
+            if not m:
+                continue
+            if ln.startswith("pack-assembly (runs in the maps) 16384") and "pack_assembly_GBps" not in out:
+                out["pack_assembly_GBps"] = float(m.group(1)) * 1e3
+                out["pack_assembly_frac"] = float(m.group(2))
+            elif ln.startswith("pack-assembly (scattered maps)"):
+                out["pack_assembly_scattered_maps_GBps"] = float(m.group(1)) * 1e3
+            elif ln.startswith("S-assembly"):
+                out["s_assembly_GBps"] = float(m.group(1)) * 1e3
+        if out:
+            out["source"] = "profiles/r03_ubench_assemble.txt (scripts/ubench/assemble_bench.hip, one launch each)"
+            return out
+    except OSError:
+        pass
+    return None
+
+
 def rooflines(per_kernel, best, workload_tag):
     """`roofline` of the kernel with the largest total time, `roofline_assembly` of k_assemble."""
     roofline = roofline_assembly = None
@@ -231,7 +260,8 @@ def rooflines(per_kernel, best, workload_tag):
                              "time_share": ka["ms"] / total_ms,
                              "note": "launches beside the updates (contribution blocks travel 32 rows at a time); "
                                      "the kernel alone on large blocks: scripts/ubench/assemble_bench.hip, "
-                                     "profiles/r03_ubench_assemble.txt"}
+                                     "profiles/r03_ubench_assemble.txt",
+                             "isolated": isolated_assembly()}
     return roofline, roofline_assembly
 
 

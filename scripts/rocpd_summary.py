@@ -117,6 +117,9 @@ def gaps(db_path):
         calls[-1].append(r)
     whole = [c for c in calls if len(c) >= 0.9 * max(len(x) for x in calls)]    # warm-up, timed and profiled steps
     big = whole[1] if len(whole) > 1 else whole[0]                              # the timed one
+    print("window: one engine call = one stage of a staged factorization (calls are split where the device sits "
+          "idle for 3 ms of host work); of the %d calls in the trace, the second of those with the most kernels"
+          % len(calls))
     print("kernels %d, span %.1f ms" % (len(big), (max(x[2] for x in big) - big[0][1]) / 1e6))
     ends = sorted(x[2] for x in big)
     byq = collections.defaultdict(list)
