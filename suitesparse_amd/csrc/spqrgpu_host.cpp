@@ -605,7 +605,47 @@ struct Buf
     ~Buf ( ) { release ( ) ; }
 } ;
 
-struct Workspaces { Buf dF, dS, dR, dR2, dAx, dTasks, dPrefix, hBounce [2] ; } ;
+struct Workspaces { Buf dF, dS, dR, dR2, dAx, dTasks, dPrefix, dLimbo, hBounce [2] ; } ;
+
+// Where contribution blocks wait on the device between groups: pieces of one grow-only buffer handed
+// out first-fit.  The same sequence of requests gets the same addresses in every factorization, so the
+// front descriptors of a later group (which name the waiting blocks of its children) are the same
+// from call to call and the engine finds the schedule it made for them (with a hipMalloc per block
+// the groups after the first were planned again in every factorization: 0.3 s each at 128^3).
+#include <map>
+struct DevArena
+{
+    char *base = NULL ; size_t cap = 0 ;
+    std::map<size_t, size_t> free_at ;          // offset -> length of every free piece
+    void reset (void *p, size_t bytes) { base = (char *) p ; cap = p ? bytes : 0 ; free_at.clear ( ) ; if (cap) free_at [0] = cap ; }
+    static size_t rounded (size_t bytes) { return (bytes + 255) & ~(size_t) 255 ; }
+    bool owns (const void *p) const { return base && (const char *) p >= base && (const char *) p < base + cap ; }
+    void *take (size_t bytes)
+    {
+        bytes = rounded (bytes) ;
+        for (auto it = free_at.begin ( ) ; it != free_at.end ( ) ; ++it)
+        {
+            if (it->second < bytes) continue ;
+            const size_t off = it->first, len = it->second ;
+            free_at.erase (it) ;
+            if (len > bytes) free_at [off + bytes] = len - bytes ;
+            return base + off ;
+        }
+        return NULL ;
+    }
+    void give (void *p, size_t bytes)
+    {
+        size_t off = (size_t) ((char *) p - base), len = rounded (bytes) ;
+        auto next = free_at.lower_bound (off) ;
+        if (next != free_at.begin ( ))
+        {
+            auto prev = std::prev (next) ;
+            if (prev->first + prev->second == off) { off = prev->first ; len += prev->second ; free_at.erase (prev) ; }
+        }
+        if (next != free_at.end ( ) && off + len == next->first) { len += next->second ; free_at.erase (next) ; }
+        free_at [off] = len ;
+    }
+} ;
 // Goes up whenever the driver gives device memory back: what was seen to fit before may not fit now.
 static uint64_t g_ws_gen = 1 ;
 
@@ -660,9 +700,10 @@ extern "C" void spqrgpu_amd_finalize (void)
     for (int d = 0 ; d < MAX_WS_DEVICES ; d++)
     {
         Workspaces &W = g_ws [d] ;
-        if (!W.dF.p && !W.dS.p && !W.dR.p && !W.dR2.p && !W.dAx.p && !W.dTasks.p && !W.dPrefix.p) continue ;
+        if (!W.dF.p && !W.dS.p && !W.dR.p && !W.dR2.p && !W.dAx.p && !W.dTasks.p && !W.dPrefix.p && !W.dLimbo.p) continue ;
         if (hipSetDevice (d) != hipSuccess) continue ;
         W.dF.release ( ) ; W.dS.release ( ) ; W.dR.release ( ) ; W.dR2.release ( ) ; W.dAx.release ( ) ; W.dTasks.release ( ) ; W.dPrefix.release ( ) ;
+        W.dLimbo.release ( ) ;
         W.hBounce [0].release ( ) ; W.hBounce [1].release ( ) ;
     }
     g_pinned_stack.clear ( ) ;
@@ -797,6 +838,8 @@ static int factorize_impl
     hostvec<double *> limbo ;           // contribution blocks waiting on the host for a later group
     hostvec<double *> limbo_dev ;       // ... or on the device, when it has the room (no PCIe round trip)
     hostvec<double *> used_dev ;        // device limbo blocks consumed by the running group
+    hostvec<size_t> used_bytes ;
+    DevArena arena ;                    // the waiting blocks' share of the device (see DevArena)
     bool registered = false ;           // the caller's stack was page-locked by this call
     // A large page-locked stack is allocated by a helper thread while this one builds the maps and lays
     // the fronts out (page-locking runs at about 28 GB/s: 0.9 s for the 25 GB of a 96^3 grid).
@@ -1133,7 +1176,7 @@ static int factorize_impl
             // device says otherwise now: everything is handed back and the fronts are grouped by what is
             // really free.  Once; a group that still does not fit is out of memory.
             if (attempt > 0 || mine || keep || nf == 0) { code = 1 ; goto done ; }
-            dF.release ( ) ; dS.release ( ) ; WS.dR.release ( ) ; WS.dR2.release ( ) ;
+            dF.release ( ) ; dS.release ( ) ; WS.dR.release ( ) ; WS.dR2.release ( ) ; WS.dLimbo.release ( ) ;
             g_ws_gen++ ;
             S->cache.fit_gen = 0 ;
             size_t free_b = 0, total_b = 0 ;
@@ -1143,6 +1186,38 @@ static int factorize_impl
             if (verbose) fprintf (stderr, "  [spqrgpu] fronts grouped again for %.2f GB\n", (double) room / 1e9) ;
             by_stage = false ;
             ngroups = greedy_groups ((size_t) (0.85 * (double) room), false) ;
+        }
+        // ---- room for the blocks that wait between groups ----------------------------------------
+        if (ngroups > 1 && getenv ("GPUQR_HOST_LIMBO") == NULL && getenv ("GPUQR_NO_LIMBO_ARENA") == NULL)
+        {
+            // most bytes waiting at any one time: a block is made when its front's group is through and
+            // given back when its parent's group is
+            hostvec<size_t> made ((size_t) ngroups, 0), gone ((size_t) ngroups, 0) ;
+            for (Long f = 0 ; f < nf ; f++)
+            {
+                if (!is_mine (f)) continue ;
+                const Long pf = Parent [f] ;
+                if (pf >= nf || !is_mine (pf) || grp [pf] == grp [f]) continue ;
+                const Long cn = (Rp [f+1] - Rp [f]) - (Super [f+1] - Super [f]) ;
+                const size_t b = DevArena::rounded ((size_t) (cm_of (f) * cn) * sizeof (double)) ;
+                if (b == 0 || grp [f] < 0 || grp [pf] < 0) continue ;
+                made [grp [f]] += b ; gone [grp [pf]] += b ;
+            }
+            size_t live = 0, peak = 0 ;
+            for (Long g = 0 ; g < ngroups ; g++) { live -= std::min (live, gone [g]) ; live += made [g] ; peak = std::max (peak, live) ; }
+            if (peak > 0)
+            {
+                const size_t want = peak + peak / 4 + ((size_t) 1 << 20) ;      // (first fit leaves holes)
+                bool have = WS.dLimbo.cap >= want ;
+                if (!have)
+                {
+                    size_t free_b = 0, total_b = 0 ;
+                    if (hipMemGetInfo (&free_b, &total_b) == hipSuccess && free_b + WS.dLimbo.cap >= want + ((size_t) 2 << 30))
+                        have = WS.dLimbo.ensure (want) == hipSuccess ;
+                    (void) hipGetLastError ( ) ;
+                }
+                if (have) arena.reset (WS.dLimbo.p, WS.dLimbo.cap) ;
+            }
         }
         TICK ("workspace allocation") ;
 
@@ -1293,6 +1368,7 @@ static int factorize_impl
                         // the block never left the device: assemble straight from where it waits
                         ch.gpuF = ch.gpuC = limbo_dev [c] ;
                         used_dev.push_back (limbo_dev [c]) ;
+                        used_bytes.push_back ((size_t) (ccm * ccn) * sizeof (double)) ;
                         limbo_dev [c] = NULL ;
                     }
                     else
@@ -1337,8 +1413,12 @@ static int factorize_impl
             num->gpuFlops += stats.flopsActual ;
             num->gpuNumKernelLaunches += stats.numLaunches ;
             num->numStagesRun++ ;
-            for (size_t i = 0 ; i < used_dev.size ( ) ; i++) (void) hipFree (used_dev [i]) ;
-            used_dev.clear ( ) ;
+            for (size_t i = 0 ; i < used_dev.size ( ) ; i++)
+            {
+                if (arena.owns (used_dev [i])) arena.give (used_dev [i], used_bytes [i]) ;
+                else (void) hipFree (used_dev [i]) ;
+            }
+            used_dev.clear ( ) ; used_bytes.clear ( ) ;
 
             if (rp)
             {
@@ -1465,7 +1545,8 @@ static int factorize_impl
                     }
                     else if (leaves_call) { L = num->Cstack + chead ; num->Cblock [f] = chead ; chead += cm * cn ; }
                     else if (cm > 0 && cn > 0 && getenv ("GPUQR_HOST_LIMBO") == NULL
-                        && hipMalloc ((void **) &limbo_dev [f], (size_t) (cm * cn) * sizeof (double)) == hipSuccess)
+                        && ((limbo_dev [f] = (double *) arena.take ((size_t) (cm * cn) * sizeof (double))) != NULL
+                            || hipMalloc ((void **) &limbo_dev [f], (size_t) (cm * cn) * sizeof (double)) == hipSuccess))
                     {
                         // room on the device: the block waits there
                         HIPCHK (hipMemcpy2DAsync (limbo_dev [f], (size_t) cn * sizeof (double), Csrc,
@@ -1628,8 +1709,8 @@ done:
     if (join_r ( ) != hipSuccess && code == 0) code = 2 ;
     if (registered) { (void) hipHostUnregister (Rstack_user) ; num->RstackPinned = 0 ; }
     for (size_t i = 0 ; i < limbo.size ( ) ; i++) host_free (limbo [i]) ;
-    for (size_t i = 0 ; i < limbo_dev.size ( ) ; i++) if (limbo_dev [i]) (void) hipFree (limbo_dev [i]) ;
-    for (size_t i = 0 ; i < used_dev.size ( ) ; i++) (void) hipFree (used_dev [i]) ;
+    for (size_t i = 0 ; i < limbo_dev.size ( ) ; i++) if (limbo_dev [i] && !arena.owns (limbo_dev [i])) (void) hipFree (limbo_dev [i]) ;
+    for (size_t i = 0 ; i < used_dev.size ( ) ; i++) if (!arena.owns (used_dev [i])) (void) hipFree (used_dev [i]) ;
     if (code != 0) { spqr_amd_numeric_free (num) ; return code ; }
     *num_out = num ;
     return 0 ;
