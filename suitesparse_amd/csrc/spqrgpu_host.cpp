@@ -478,6 +478,10 @@ static int build_numeric_cache (const spqr_amd_symbolic *S, const int64_t *Ap, c
 // per process, until spqrgpu_amd_finalize): page-locking 25 GB for the stack of a 96^3 grid costs
 // 30-100 ms per factorization, 900 ms the first time.
 #include <mutex>
+#include <atomic>
+// Host memory this driver holds page-locked for R stacks at this moment, whole stacks and locked ends of
+// pageable ones, kept ones included: what the limit below is held against.
+static std::atomic<long long> g_locked_now (0) ;
 struct PinnedStackCache
 {
     std::mutex lock ;
@@ -494,21 +498,21 @@ struct PinnedStackCache
     }
     void give (void *p, size_t bytes)
     {
-        void *drop = NULL ;
+        void *drop = NULL ; size_t drop_bytes = 0 ;
         {
             std::lock_guard<std::mutex> g (lock) ;
             for (size_t i = 0 ; i < lent.size ( ) ; i++)
                 if (lent [i].first == p) { bytes = lent [i].second ; lent.erase (lent.begin ( ) + i) ; break ; }
-            drop = kept ;
+            drop = kept ; drop_bytes = kept_bytes ;
             kept = p ; kept_bytes = bytes ;
         }
-        if (drop) (void) hipHostFree (drop) ;
+        if (drop) { (void) hipHostFree (drop) ; g_locked_now -= (long long) drop_bytes ; }
     }
     void clear ( )
     {
-        void *drop = NULL ;
-        { std::lock_guard<std::mutex> g (lock) ; drop = kept ; kept = NULL ; kept_bytes = 0 ; }
-        if (drop) (void) hipHostFree (drop) ;
+        void *drop = NULL ; size_t drop_bytes = 0 ;
+        { std::lock_guard<std::mutex> g (lock) ; drop = kept ; drop_bytes = kept_bytes ; kept = NULL ; kept_bytes = 0 ; }
+        if (drop) { (void) hipHostFree (drop) ; g_locked_now -= (long long) drop_bytes ; }
     }
 } ;
 static PinnedStackCache g_pinned_stack ;
@@ -519,40 +523,99 @@ static PinnedStackCache g_pinned_stack ;
 // that one kept across a change of hooks is freed by what allocated it.
 struct PageableStackCache
 {
-    static const size_t min_bytes = (size_t) 1 << 30 ;
+    // (GPUQR_KEEP_PAGEABLE_FROM_MB: testing, the size from which a pageable stack is one of these)
+    static size_t min_bytes (void)
+    {
+        static size_t v = 0 ; static bool read = false ;
+        if (!read) { const char *e = getenv ("GPUQR_KEEP_PAGEABLE_FROM_MB") ; v = e ? (size_t) atol (e) << 20 : (size_t) 1 << 30 ; read = true ; }
+        return v ;
+    }
+    struct Item { void *p ; size_t bytes ; char *locked ; size_t locked_bytes ; } ;
     std::mutex lock ;
-    void *kept = NULL ; size_t kept_bytes = 0 ;
-    std::vector<std::pair<void *, size_t> > lent ;
+    Item kept = {NULL, 0, NULL, 0} ;
+    std::vector<Item> lent ;
+    static void let_go (Item &it)
+    {
+        if (it.locked) { (void) hipHostUnregister (it.locked) ; (void) hipGetLastError ( ) ; g_locked_now -= (long long) it.locked_bytes ; }
+        if (it.p) free (it.p) ;
+        it = Item {NULL, 0, NULL, 0} ;
+    }
     void *get (size_t bytes)
     {
         std::lock_guard<std::mutex> g (lock) ;
-        void *p = NULL ; size_t have = 0 ;
-        if (kept && kept_bytes >= bytes && kept_bytes <= 2 * bytes + ((size_t) 64 << 20)) { p = kept ; have = kept_bytes ; kept = NULL ; kept_bytes = 0 ; }
-        else { p = malloc (bytes) ; have = bytes ; }
-        if (!p) return NULL ;
-        try { lent.push_back (std::make_pair (p, have)) ; } catch (...) { free (p) ; return NULL ; }
-        return p ;
+        Item it = {NULL, 0, NULL, 0} ;
+        if (kept.p && kept.bytes >= bytes && kept.bytes <= 2 * bytes + ((size_t) 64 << 20)) { it = kept ; kept = Item {NULL, 0, NULL, 0} ; }
+        else { it.p = malloc (std::max (bytes, (size_t) 1)) ; it.bytes = bytes ; }
+        if (!it.p) return NULL ;
+        try { lent.push_back (it) ; } catch (...) { let_go (it) ; return NULL ; }
+        return it.p ;
     }
     bool give (void *p)                 // false: not one of these stacks
     {
-        void *drop = NULL ;
+        Item drop = {NULL, 0, NULL, 0} ;
         {
             std::lock_guard<std::mutex> g (lock) ;
             size_t i = 0 ;
-            while (i < lent.size ( ) && lent [i].first != p) i++ ;
+            while (i < lent.size ( ) && lent [i].p != p) i++ ;
             if (i == lent.size ( )) return false ;
             drop = kept ;
-            kept = p ; kept_bytes = lent [i].second ;
+            kept = lent [i] ;
             lent.erase (lent.begin ( ) + i) ;
         }
-        if (drop) free (drop) ;
+        let_go (drop) ;
         return true ;
+    }
+    // Page-lock [lo, lo + bytes) of a stack that is out on loan, so that packed R can be sent there by DMA
+    // from inside the engine.  A range locked before stays locked if it is the same one (the stack of
+    // the factorization before, same problem), and is let go otherwise.
+    bool lock_range (void *stack, char *lo, size_t bytes)
+    {
+        Item it = {NULL, 0, NULL, 0} ;
+        {
+            std::lock_guard<std::mutex> g (lock) ;
+            for (size_t i = 0 ; i < lent.size ( ) ; i++) if (lent [i].p == stack) it = lent [i] ;
+        }
+        if (!it.p) return false ;
+        if (it.locked == lo && it.locked_bytes == bytes) return true ;
+        if (it.locked)
+        {
+            (void) hipHostUnregister (it.locked) ; (void) hipGetLastError ( ) ;
+            g_locked_now -= (long long) it.locked_bytes ;
+            it.locked = NULL ; it.locked_bytes = 0 ;
+        }
+        if (bytes > 0 && hipHostRegister (lo, bytes, hipHostRegisterDefault) == hipSuccess)
+        {
+            it.locked = lo ; it.locked_bytes = bytes ;
+            g_locked_now += (long long) bytes ;
+        }
+        else (void) hipGetLastError ( ) ;
+        {
+            std::lock_guard<std::mutex> g (lock) ;
+            for (size_t i = 0 ; i < lent.size ( ) ; i++) if (lent [i].p == stack) lent [i] = it ;
+        }
+        return it.locked != NULL ;
+    }
+    size_t locked_of (void *stack)
+    {
+        std::lock_guard<std::mutex> g (lock) ;
+        for (size_t i = 0 ; i < lent.size ( ) ; i++) if (lent [i].p == stack) return lent [i].locked_bytes ;
+        return 0 ;
+    }
+    void unlock_kept ( )                // the kept stack stays, what was page-locked of it is let go
+    {
+        std::lock_guard<std::mutex> g (lock) ;
+        if (kept.locked)
+        {
+            (void) hipHostUnregister (kept.locked) ; (void) hipGetLastError ( ) ;
+            g_locked_now -= (long long) kept.locked_bytes ;
+            kept.locked = NULL ; kept.locked_bytes = 0 ;
+        }
     }
     void clear ( )
     {
-        void *drop = NULL ;
-        { std::lock_guard<std::mutex> g (lock) ; drop = kept ; kept = NULL ; kept_bytes = 0 ; }
-        if (drop) free (drop) ;
+        Item drop = {NULL, 0, NULL, 0} ;
+        { std::lock_guard<std::mutex> g (lock) ; drop = kept ; kept = Item {NULL, 0, NULL, 0} ; }
+        let_go (drop) ;
     }
 } ;
 static PageableStackCache g_pageable_stack ;
@@ -573,6 +636,17 @@ static size_t pin_limit_bytes (void)
         limit = (size_t) (gib * 1073741824.0) ;
     }
     return limit ;
+}
+
+// Is there room for `bytes` more of page-locked memory under the limit?  Stacks that are only kept for a
+// next factorization make way first.
+static bool pin_room (size_t bytes)
+{
+    const long long limit = (long long) pin_limit_bytes ( ) ;
+    if ((long long) bytes + g_locked_now.load ( ) <= limit) return true ;
+    g_pinned_stack.clear ( ) ;
+    g_pageable_stack.unlock_kept ( ) ;
+    return (long long) bytes + g_locked_now.load ( ) <= limit ;
 }
 
 extern "C" void spqr_amd_numeric_free (spqr_amd_numeric *num)
@@ -840,6 +914,12 @@ static int factorize_impl
     hostvec<double *> used_dev ;        // device limbo blocks consumed by the running group
     hostvec<size_t> used_bytes ;
     DevArena arena ;                    // the waiting blocks' share of the device (see DevArena)
+    // A pageable stack (one beyond the page-locking limit) with its last groups' share page-locked: those
+    // groups send their R from inside the engine, the groups before them through the bounce buffers.
+    bool stack_kept_kind = false ;      // the stack is one of g_pageable_stack's
+    Long tail_first = -1 ;              // first group whose R lies in the page-locked end of the stack (-1: none)
+    bool tail_locked = false ;
+    std::thread lock_thread ;
     bool registered = false ;           // the caller's stack was page-locked by this call
     // A large page-locked stack is allocated by a helper thread while this one builds the maps and lays
     // the fronts out (page-locking runs at about 28 GB/s: 0.9 s for the 25 GB of a 96^3 grid).
@@ -903,9 +983,12 @@ static int factorize_impl
             num->Rstack = Rstack_user ;
             num->RstackBorrowed = 1 ;
             if (rtotal > 0 && getenv ("GPUQR_PAGEABLE_R") == NULL
-                && (size_t) rtotal * sizeof (double) <= pin_limit_bytes ( )
+                && pin_room ((size_t) rtotal * sizeof (double))
                 && hipHostRegister (Rstack_user, (size_t) rtotal * sizeof (double), hipHostRegisterDefault) == hipSuccess)
+            {
                 registered = true ;
+                g_locked_now += (long long) ((size_t) rtotal * sizeof (double)) ;
+            }
             else { (void) hipGetLastError ( ) ; num->RstackPinned = 0 ; }
         }
         else
@@ -916,22 +999,24 @@ static int factorize_impl
         }
         else
         if (getenv ("GPUQR_PAGEABLE_R") == NULL && (size_t) rtotal * sizeof (double) >= ((size_t) 256 << 20)
-            && (size_t) rtotal * sizeof (double) <= pin_limit_bytes ( )
+            && pin_room ((size_t) rtotal * sizeof (double))
             && (pin_job.start ((size_t) rtotal * sizeof (double)), pin_job.started))
         {
             // (joined below, before the first use of the stack)
         }
         else
         if (getenv ("GPUQR_PAGEABLE_R") != NULL       // test knob: take the fallback path
-            || (size_t) rtotal * sizeof (double) > pin_limit_bytes ( )
+            || !pin_room ((size_t) std::max ((Long) 1, rtotal) * sizeof (double))
             || hipHostMalloc ((void **) &num->Rstack, (size_t) std::max ((Long) 1, rtotal) * sizeof (double), hipHostMallocDefault) != hipSuccess)
         {
             (void) hipGetLastError ( ) ;
             num->RstackPinned = 0 ;
             const size_t rbytes = (size_t) std::max ((Long) 1, rtotal) * sizeof (double) ;
-            num->Rstack = (double *) (rbytes >= PageableStackCache::min_bytes ? g_pageable_stack.get (rbytes) : host_malloc (rbytes)) ;
+            stack_kept_kind = rbytes >= PageableStackCache::min_bytes ( ) ;
+            num->Rstack = (double *) (stack_kept_kind ? g_pageable_stack.get (rbytes) : host_malloc (rbytes)) ;
             if (!num->Rstack) { code = 1 ; goto done ; }
         }
+        else g_locked_now += (long long) ((size_t) std::max ((Long) 1, rtotal) * sizeof (double)) ;     // (page-locked here and now)
         num->Rblock = (Long *) host_malloc ((size_t) std::max ((Long) 1, nf) * sizeof (Long)) ;
         num->Rdead = (char *) host_calloc ((size_t) std::max ((Long) 1, n), 1) ;
         if (!num->Rblock || !num->Rdead) { code = 1 ; goto done ; }
@@ -1129,7 +1214,11 @@ static int factorize_impl
         {
             pin_job.join ( ) ;
             pin_job.started = false ;
-            if (pin_job.ok) { num->Rstack = (double *) pin_job.ptr ; pin_job.ptr = NULL ; }
+            if (pin_job.ok)
+            {
+                num->Rstack = (double *) pin_job.ptr ; pin_job.ptr = NULL ;
+                g_locked_now += (long long) ((size_t) std::max ((Long) 1, rtotal) * sizeof (double)) ;
+            }
             else
             {
                 num->RstackPinned = 0 ;
@@ -1219,6 +1308,35 @@ static int factorize_impl
                 if (have) arena.reset (WS.dLimbo.p, WS.dLimbo.cap) ;
             }
         }
+        // ---- the end of a pageable stack, page-locked ---------------------------------------------
+        if (stack_kept_kind && !num->RstackPinned && ngroups > 1 && !keep && !rp
+            && getenv ("GPUQR_LATE_R") == NULL && getenv ("GPUQR_PAGEABLE_R") == NULL)
+        {
+            hostvec<Long> rs ((size_t) ngroups, 0) ;
+            for (Long g = 0 ; g < ngroups ; g++) { layout_group (g, false) ; rs [g] = rsum ; }
+            // (under the limit, together with what else is page-locked now; a page-locked stack that is only
+            // kept for a next factorization makes way)
+            g_pinned_stack.clear ( ) ;
+            const long long others = g_locked_now.load ( ) - (long long) g_pageable_stack.locked_of (num->Rstack) ;
+            const long long budget = (long long) pin_limit_bytes ( ) - std::max (others, (long long) 0) ;
+            Long tail = 0, g0 = ngroups ;
+            while (g0 > 0 && (long long) ((size_t) (tail + rs [g0-1]) * sizeof (double)) <= budget) { tail += rs [g0-1] ; g0-- ; }
+            if (g0 < ngroups && tail > 0)
+            {
+                Long before = 0 ;
+                for (Long g = 0 ; g < g0 ; g++) before += rs [g] ;
+                char *lo = (char *) (num->Rstack + before) ;
+                const size_t bytes = (size_t) tail * sizeof (double) ;
+                void *stack = num->Rstack ;
+                bool *okp = &tail_locked ;
+                tail_first = g0 ;
+                // (beside the first groups: page-locking touches every page of the range)
+                try { lock_thread = std::thread ([stack, lo, bytes, okp, wdev] ( ) { if (hipSetDevice (wdev) == hipSuccess) *okp = g_pageable_stack.lock_range (stack, lo, bytes) ; }) ; }
+                catch (...) { tail_locked = g_pageable_stack.lock_range (stack, lo, bytes) ; }
+                if (verbose) fprintf (stderr, "  [spqrgpu] R of groups %ld..%ld goes out from inside the engine: %.3f GB at the end of the pageable stack page-locked\n",
+                    (long) g0, (long) (ngroups - 1), (double) bytes / 1e9) ;
+            }
+        }
         TICK ("workspace allocation") ;
 
         Long rhead = 0, chead = 0 ;
@@ -1230,6 +1348,10 @@ static int factorize_impl
         hostvec<Long> rows_at ;
         for (Long g = 0 ; g < ngroups ; g++)
         {
+            // this group's R: from inside the engine (the stack, or its end from this group on, is page-locked)
+            // or packed and copied once the group is through
+            if (g == tail_first && lock_thread.joinable ( )) lock_thread.join ( ) ;
+            const bool rie = r_in_engine || (tail_first >= 0 && g >= tail_first && tail_locked) ;
             // ---- fronts of the group, in postorder -----------------------------------------
             layout_group (g, true) ;
             const Long numFronts = (Long) list.size ( ) ;
@@ -1272,6 +1394,9 @@ static int factorize_impl
                     for (Long k = 0 ; k < numFronts ; k++) if (fronts [k].cpuRpack != NULL) fronts [k].cpuRpack = num->Rstack + rhead + ROff [k] ;
             }
 
+            // (the engine is about to pack into this group's block of packed R: a helper thread still copying
+            // an earlier group's R out of that block comes first)
+            if (rie && !r_in_engine && r_thread_src == dR.p && join_r ( ) != hipSuccess) { code = 2 ; goto done ; }
             HIPCHK (hipMemsetAsync (F0, 0, (size_t) std::max ((Long) 1, fsum) * sizeof (double), 0)) ;
             // S entries of the group, built on the device; runs of fronts that are neighbours in
             // postorder go in one launch
@@ -1310,7 +1435,7 @@ static int factorize_impl
                     rows_at [k] = rows_off ;
                     rows_off += (frank + cm_of (f)) * fn ;
                 }
-                else if (r_in_engine)
+                else if (rie)
                 {
                     // the engine packs the block once the front is final and sends it while the rest runs
                     fr.gpuRpack = (double *) dR.p + ROff [k] ;
@@ -1462,7 +1587,7 @@ static int factorize_impl
             }
 
             // ---- R: packed on the device, one copy onto the stack ---------------------------------
-            if (r_in_engine)
+            if (rie)
             {
                 for (Long k = 0 ; k < numFronts ; k++) num->Rblock [list [k]] = rhead + ROff [k] ;
                 rhead += rsum ;
@@ -1706,8 +1831,14 @@ static int factorize_impl
     }
 
 done:
+    if (lock_thread.joinable ( )) lock_thread.join ( ) ;
     if (join_r ( ) != hipSuccess && code == 0) code = 2 ;
-    if (registered) { (void) hipHostUnregister (Rstack_user) ; num->RstackPinned = 0 ; }
+    if (registered)
+    {
+        (void) hipHostUnregister (Rstack_user) ;
+        g_locked_now -= (long long) ((size_t) num->rsize * sizeof (double)) ;
+        num->RstackPinned = 0 ;
+    }
     for (size_t i = 0 ; i < limbo.size ( ) ; i++) host_free (limbo [i]) ;
     for (size_t i = 0 ; i < limbo_dev.size ( ) ; i++) if (limbo_dev [i] && !arena.owns (limbo_dev [i])) (void) hipFree (limbo_dev [i]) ;
     for (size_t i = 0 ; i < used_dev.size ( ) ; i++) if (!arena.owns (used_dev [i])) (void) hipFree (used_dev [i]) ;

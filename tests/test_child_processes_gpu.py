@@ -133,3 +133,20 @@ def test_stage_without_r_between_two_stages_in_a_fresh_process():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sweeps", "dbg", "binding_race.py"), "10371", "5000000"],
                        env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("shape,mem,limit_gib", [("20x20x20", 80_000_000, 0.0112), ("96x96", 20_000_000, 0.0028), ("96x96", 10_000_000, 0.0028)])
+def test_end_of_a_pageable_stack_page_locked(shape, mem, limit_gib):
+    """An R stack beyond the page-locking limit is pageable; the driver page-locks as much of its end as
+    the limit allows, and the groups whose R lies there send it from inside the engine while the groups
+    before them go through the bounce buffers.  Exercised at a small size by a process with a tiny limit
+    (read once per process): same bits as the one-stage run, and the log says the mixed hand-off ran."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GPUQR_PIN_LIMIT_GIB=str(limit_gib), GPUQR_KEEP_PAGEABLE_FROM_MB="0", GPUQR_VERBOSE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tail_worker.py"), shape, str(mem)],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "same bits in all runs" in r.stdout
+    said = [ln for ln in r.stderr.splitlines() if "goes out from inside the engine" in ln]
+    assert len(said) == 2, r.stderr[-3000:]          # the two runs without GPUQR_LATE_R
