@@ -494,6 +494,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
+    # The ranks of one node share the host's page-locked memory: the driver's per-process limit for R
+    # stacks (48 GiB) is divided among them (a stack beyond it is pageable, with its end page-locked).
+    nranks = int(os.environ.get("WORLD_SIZE", "1"))
+    if nranks > 1:
+        os.environ.setdefault("GPUQR_PIN_LIMIT_GIB", "%.3f" % (48.0 / nranks))
+
     import torch
     import torch.distributed as dist
 

@@ -1264,10 +1264,13 @@ static int factorize_impl
             // The stages were taken to fit (an earlier call found them to, or the estimate said so) and the
             // device says otherwise now: everything is handed back and the fronts are grouped by what is
             // really free.  Once; a group that still does not fit is out of memory.
-            if (attempt > 0 || mine || keep || nf == 0) { code = 1 ; goto done ; }
+            if (attempt > 0 || nf == 0) { code = 1 ; goto done ; }
             dF.release ( ) ; dS.release ( ) ; WS.dR.release ( ) ; WS.dR2.release ( ) ; WS.dLimbo.release ( ) ;
             g_ws_gen++ ;
             S->cache.fit_gen = 0 ;
+            // (a call for a subset of the fronts, or one that keeps H, cannot be cut differently: it tries once
+            // more with every buffer of earlier calls given back, the waiting blocks' included)
+            if (mine || keep) continue ;
             size_t free_b = 0, total_b = 0 ;
             if (hipMemGetInfo (&free_b, &total_b) != hipSuccess) { (void) hipGetLastError ( ) ; code = 1 ; goto done ; }
             const size_t margin = (size_t) 1 << 30 ;
