@@ -171,6 +171,12 @@ int64_t gpuqr_front_flops (int64_t fm, int64_t fn, const int64_t *Stair);
  * normal mode's (same tasks, same order within a stream). */
 void gpuqr_set_serial (int on);
 
+/* Number of schedules planned in this process so far.  A call whose problem (shapes, staircases, tree,
+ * device pointers) the engine has seen before replays the schedule it kept on the device and plans
+ * nothing; a caller that factorizes again can see from this counter whether that happened.  No
+ * counterpart in the reference, which plans every launch anew. */
+int64_t gpuqr_schedules_built (void);
+
 /* Device memory the engine itself allocates for one fm-by-fn front beyond the front (task records,
  * workgroup list, VT tiles), an upper bound.  The reference prices its queue and VT pools inside
  * spqrgpu_computeFrontStaging (SPQR/SPQRGPU/spqrgpu_computeFrontStaging.cpp:90-118,161-164) with the

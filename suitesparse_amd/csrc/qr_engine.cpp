@@ -1398,8 +1398,14 @@ template <class Body> static void run_chunks (int64_t n, Body body)
 
 // Validate the fronts, order them children first, emit their tasks and sort the workgroups by
 // (round, launch slot).  Host work only.
+// How many schedules this process has planned so far (a call that finds the schedule of an earlier call
+// on the device plans nothing): lets a caller see whether its re-factorizations replay.
+static std::atomic<long long> g_schedules_built (0) ;
+extern "C" int64_t gpuqr_schedules_built (void) { return (int64_t) g_schedules_built.load ( ) ; }
+
 static int build_schedule (gpuqr_front *fronts, int64_t nf, Schedule &sc, const bool eng_verbose, double &eng_tlast)
 {
+    g_schedules_built++ ;
     Plan &plan = sc.plan ;
     hvec<int32_t> &done_last = sc.done_last, &bdep = sc.bdep ;
     hvec<int64_t> &rptr = sc.rptr ;

@@ -257,6 +257,33 @@ def test_r_packed_inside_the_engine_equals_r_packed_afterwards(monkeypatch, grid
     assert r0.R.nnz == r1.R.nnz
 
 
+def test_staged_refactorization_plans_nothing():
+    """A factorization in several stages is several engine calls; from the second factorization on each
+    of them must find the schedule it made the first time.  That needs the same front descriptors,
+    and those of a later stage name the device blocks in which the contributions of earlier stages
+    wait: the driver hands those blocks out of one buffer, first-fit, so they land at the same
+    addresses every time."""
+    import ctypes as C
+    from suitesparse_amd import _lib
+    L = _lib.lib()
+    L.gpuqr_schedules_built.restype = C.c_int64
+    A = problems.stacked_ls((20, 20, 20))
+    Q = problems.nested_dissection((20, 20, 20), leaf=3)
+    sym = spqr.analyze(A, Q, relax=-1, gpuMemorySize=80_000_000)
+    assert sym.numStages >= 4
+    n0 = L.gpuqr_schedules_built()
+    r1 = spqr.factorize(sym, A)
+    n1 = L.gpuqr_schedules_built()
+    assert n1 - n0 == r1.numStagesRun >= sym.numStages
+    A2 = A.copy()
+    A2.data = A2.data * 1.5
+    r2 = spqr.factorize(sym, A2)
+    r3 = spqr.factorize(sym, A)
+    assert L.gpuqr_schedules_built() == n1                  # nothing planned again
+    assert (r3.R != r1.R).nnz == 0
+    assert abs(abs(r2.R) - 1.5 * abs(r1.R)).max() <= 1e-12 * abs(r2.R).max()
+
+
 def test_repeated_factorizations_reuse_the_schedule_and_follow_the_values(monkeypatch):
     """A second factorization on the same symbolic object replays the engine's schedule; it must
     track new values, survive other engine calls in between, and agree with the uncached path."""
