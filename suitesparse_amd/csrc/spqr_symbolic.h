@@ -68,6 +68,13 @@ struct spqr_amd_symbolic
         hostvec<gpuqr_front> fronts ;       // the front descriptors of a single-group factorization ...
         uint64_t fronts_key = 0 ;           // ... made for the workspaces this key stands for
         const double *fronts_rstack = NULL ;    // ... and for R blocks delivered to this stack
+        // ... and where that group's fronts, S entries and R blocks lie in their arenas
+        bool lay_ok = false ;
+        int64_t lay_line_from = -1 ;            // (the row-pitch rule the layout was made under)
+        hostvec<int64_t> lay_list, lay_FOff, lay_SOff, lay_ROff, lay_rel ;
+        int64_t lay_fsum = 0, lay_ssum = 0, lay_rsum = 0 ;
+        hostvec<int64_t> lay_sruns ;            // runs of fronts whose S entries are built by one launch: (first front, entries) pairs
+        bool lay_sruns_ok = false ;
     } ;
     mutable NumericCache cache ;
     ~spqr_amd_symbolic ( ) { if (cache.release) cache.release (&cache) ; }

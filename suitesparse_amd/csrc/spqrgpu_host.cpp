@@ -287,6 +287,10 @@ static void release_numeric_cache (spqr_amd_symbolic::NumericCache *c)
     c->stage_worst_known = false ; c->fit_gen = 0 ;
     c->fronts_key = 0 ; c->fronts_rstack = NULL ;
     hostvec<gpuqr_front> ( ).swap (c->fronts) ;
+    c->lay_ok = false ; c->lay_sruns_ok = false ;
+    hostvec<int64_t> ( ).swap (c->lay_sruns) ;
+    hostvec<int64_t> ( ).swap (c->lay_list) ; hostvec<int64_t> ( ).swap (c->lay_FOff) ; hostvec<int64_t> ( ).swap (c->lay_SOff) ;
+    hostvec<int64_t> ( ).swap (c->lay_ROff) ; hostvec<int64_t> ( ).swap (c->lay_rel) ;
 }
 
 // Maps, staircases and the destination / source of every S entry: pattern only, so done once per
@@ -1046,6 +1050,7 @@ static int factorize_impl
         TICK ("maps + S pattern (cached)") ;
         if (dAx.ensure ((size_t) std::max ((Long) 1, S->anz) * sizeof (double)) != hipSuccess) { code = 1 ; goto done ; }
         if (S->anz > 0) HIPCHK (hipMemcpyAsync (dAx.p, Ax, (size_t) S->anz * sizeof (double), hipMemcpyHostToDevice, 0)) ;
+        TICK ("values to the device") ;
 
         limbo.assign ((size_t) std::max ((Long) 1, nf), (double *) NULL) ;
         limbo_dev.assign ((size_t) std::max ((Long) 1, nf), (double *) NULL) ;
@@ -1180,6 +1185,19 @@ static int factorize_impl
         auto child_in_place = [&] (Long c) { return (mine && !mine [c]) ? limbo_in_dev : (limbo_dev [c] != NULL) ; } ;
         auto layout_group = [&] (Long g, bool final_pass)
         {
+            // One group that is the one stage of the analysis, nothing that changes sizes from call to call
+            // (no rank plan, no subset, no right-hand-side block): the layout follows from the symbolic
+            // object alone and is kept with it (two passes over the 110,287 fronts of the 2D 1024^2 problem
+            // were 10 of a re-factorization's 80 ms).
+            spqr_amd_symbolic::NumericCache &NCl = S->cache ;
+            const bool lay_cacheable = by_stage && ngroups == 1 && g == 0 && !rp && !mine && !keep && nf > 0 ;
+            if (lay_cacheable && NCl.lay_ok && NCl.lay_line_from == line_from)
+            {
+                list = NCl.lay_list ; FOff = NCl.lay_FOff ; SOff = NCl.lay_SOff ; ROff = NCl.lay_ROff ;
+                fsum = NCl.lay_fsum ; ssum = NCl.lay_ssum ; rsum = NCl.lay_rsum ; nlimbo = 0 ;
+                if (final_pass) rel = NCl.lay_rel ;
+                return ;
+            }
             list.clear ( ) ;
             if (!by_stage) { for (Long k = 0 ; k < nf ; k++) if (grp [Post [k]] == g) list.push_back (Post [k]) ; }
             else for (Long p = S->Stagingp [g] ; p < S->Stagingp [g+1] ; p++) list.push_back (Post [p]) ;
@@ -1207,8 +1225,15 @@ static int factorize_impl
                 ssum += S_count (f) ;
                 rsum += rsize_of (f) ;
             }
+            if (lay_cacheable && final_pass && nlimbo == 0)
+            {
+                NCl.lay_list = list ; NCl.lay_FOff = FOff ; NCl.lay_SOff = SOff ; NCl.lay_ROff = ROff ; NCl.lay_rel = rel ;
+                NCl.lay_fsum = fsum ; NCl.lay_ssum = ssum ; NCl.lay_rsum = rsum ;
+                NCl.lay_line_from = line_from ; NCl.lay_ok = true ;
+            }
         } ;
 
+        TICK ("groups") ;
         // ---- the page-locked stack, if a helper thread went for it -------------------------------
         if (pin_job.started)
         {
@@ -1400,19 +1425,37 @@ static int factorize_impl
             // (the engine is about to pack into this group's block of packed R: a helper thread still copying
             // an earlier group's R out of that block comes first)
             if (rie && !r_in_engine && r_thread_src == dR.p && join_r ( ) != hipSuccess) { code = 2 ; goto done ; }
+            TICK ("  group: layout") ;
             HIPCHK (hipMemsetAsync (F0, 0, (size_t) std::max ((Long) 1, fsum) * sizeof (double), 0)) ;
             // S entries of the group, built on the device; runs of fronts that are neighbours in
             // postorder go in one launch
-            for (Long k = 0 ; k < numFronts ; )
             {
-                Long k2 = k, cnt = 0 ;
-                while (k2 < numFronts && SGlob [list [k2]] == SGlob [list [k]] + cnt) { cnt += S_count (list [k2]) ; k2++ ; }
-                if (cnt > 0)
+                // (the runs are kept with the layout where that is kept: see layout_group)
+                spqr_amd_symbolic::NumericCache &NCl = S->cache ;
+                const bool keep_runs = by_stage && ngroups == 1 && !rp && !mine && !keep && NCl.lay_ok ;
+                hostvec<Long> runs_now ;
+                hostvec<Long> &runs = (keep_runs ? NCl.lay_sruns : runs_now) ;
+                if (!(keep_runs && NCl.lay_sruns_ok))
+                {
+                    runs.clear ( ) ;
+                    for (Long k = 0 ; k < numFronts ; )
+                    {
+                        Long k2 = k, cnt = 0 ;
+                        while (k2 < numFronts && SGlob [list [k2]] == SGlob [list [k]] + cnt) { cnt += S_count (list [k2]) ; k2++ ; }
+                        if (cnt > 0) { runs.push_back (k) ; runs.push_back (cnt) ; }
+                        k = k2 ;
+                    }
+                    if (keep_runs) NCl.lay_sruns_ok = true ;
+                }
+                for (size_t i = 0 ; i + 1 < runs.size ( ) ; i += 2)
+                {
+                    const Long k = runs [i], cnt = runs [i+1] ;
                     HIPCHK (qr_launch_build_s (S0 + SOff [k], (const long long *) (rp ? rp->d_findex : NC.d_findex) + SGlob [list [k]],
                         (const long long *) NC.d_aperm + SGlob [list [k]], (const double *) dAx.p, cnt, 0)) ;
-                k = k2 ;
+                }
             }
 
+            TICK ("  group: zero fill and S launches") ;
             Long next_child = numFronts ;
             for (Long k = 0 ; k < numFronts && !reuse_fronts ; k++)
             {
