@@ -77,7 +77,15 @@ struct spqr_amd_symbolic
         bool lay_sruns_ok = false ;
     } ;
     mutable NumericCache cache ;
-    ~spqr_amd_symbolic ( ) { if (cache.release) cache.release (&cache) ; }
+    // The per-device copies of this object that spqrgpu_amd_factorize_multi works on (each with a numeric
+    // cache on its device), kept from one factorization to the next; owned and released by that file.
+    mutable void *multi_copies = NULL ;
+    mutable void (*multi_release) (void *) = NULL ;
+    ~spqr_amd_symbolic ( )
+    {
+        if (multi_copies && multi_release) multi_release (multi_copies) ;
+        if (cache.release) cache.release (&cache) ;
+    }
 } ;
 
 #endif

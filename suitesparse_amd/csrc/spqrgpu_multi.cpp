@@ -197,6 +197,20 @@ static spqr_amd_symbolic *clone_symbolic (const spqr_amd_symbolic *S)
     return C ;
 }
 
+// The copies live with the object they were made from: a second factorization on the same symbolic
+// object finds their assembly maps, S permutations and schedules where the first left them.
+struct MultiCopies { std::vector<spqr_amd_symbolic *> of_device ; } ;
+static void release_multi_copies (void *p)
+{
+    MultiCopies *mc = (MultiCopies *) p ;
+    int cur = 0 ;
+    (void) hipGetDevice (&cur) ;
+    for (size_t d = 0 ; d < mc->of_device.size ( ) ; d++)
+        if (mc->of_device [d]) { (void) hipSetDevice ((int) d) ; spqr_amd_symbolic_free (mc->of_device [d]) ; }
+    (void) hipSetDevice (cur) ;
+    delete mc ;
+}
+
 namespace
 {
 struct Call                     // one subset call: the fronts (part, level)
@@ -247,7 +261,14 @@ extern "C" int spqrgpu_amd_factorize_multi
         if ((code = spqr_amd_map_tree (S, ndev, owner.data ( ), level.data ( ), NULL, NULL)) != 0) throw code ;
         Long nlev = 0 ;
         for (Long f = 0 ; f < nf ; f++) nlev = std::max (nlev, level [f] + 1) ;
-        for (int k = 0 ; k < ndev ; k++) if (!symdev [dev [k]]) symdev [dev [k]] = clone_symbolic (S) ;
+        if (!S->multi_copies) { S->multi_copies = new MultiCopies ( ) ; S->multi_release = release_multi_copies ; }
+        MultiCopies *mc = (MultiCopies *) S->multi_copies ;
+        if (mc->of_device.size ( ) < (size_t) ndevices_here) mc->of_device.resize ((size_t) ndevices_here, (spqr_amd_symbolic *) NULL) ;
+        for (int k = 0 ; k < ndev ; k++)
+        {
+            if (!mc->of_device [dev [k]]) mc->of_device [dev [k]] = clone_symbolic (S) ;
+            symdev [dev [k]] = mc->of_device [dev [k]] ;
+        }
         // peer access between the devices that will exchange blocks (an error here only means the copies
         // go through the host, or that access was enabled before)
         for (int a = 0 ; a < ndev ; a++)
@@ -407,8 +428,7 @@ extern "C" int spqrgpu_amd_factorize_multi
         if (calls [i].cout) { (void) hipSetDevice (dev [calls [i].part]) ; (void) hipFree (calls [i].cout) ; }
     }
     for (size_t i = 0 ; i < peer_blocks.size ( ) ; i++) if (peer_blocks [i]) (void) hipFree (peer_blocks [i]) ;
-    for (int d = 0 ; d < ndevices_here ; d++)
-        if (symdev [d]) { (void) hipSetDevice (d) ; spqr_amd_symbolic_free (symdev [d]) ; }
+    // (the per-device copies stay with S for its next factorization)
     (void) hipSetDevice (cur_dev) ;
     if (code != 0) { if (num) spqr_amd_numeric_free (num) ; return code ; }
     *num_out = num ;

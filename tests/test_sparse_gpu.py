@@ -627,6 +627,9 @@ def test_one_process_multi_device_entry_point_gives_the_single_device_r(shape, l
     res = multigpu.factorize_multi(sym, A, parts, devices=[0] * parts)
     assert res.rank == res0.rank == sym.n
     assert (res.R != res0.R).nnz == 0
+    # once more on the same symbolic object (its per-device copies, maps and schedules are kept with it)
+    res_again = multigpu.factorize_multi(sym, A, parts, devices=[0] * parts)
+    assert (res_again.R != res0.R).nnz == 0
     # the same with the values in S order and no A at all: what the SPQR adapter's cc->numGPU branch passes
     res_sx = multigpu.factorize_multi(sym, None, parts, devices=[0] * parts, Sx=spqr.s_values(sym, A))
     assert (res_sx.R != res0.R).nnz == 0
