@@ -22,7 +22,7 @@ case $PASS in
 kt)
   timeout -s KILL 1000 rocprofv3 --kernel-trace --stats -d /tmp/p_kt -- python3 $B > "$OUT/${TAG}_kt_line.json" 2> "$OUT/${TAG}_kt.err"
   python3 $S stats "$(db /tmp/p_kt)" "$OUT/${TAG}_kernel_stats.csv"
-  python3 $S gaps "$(db /tmp/p_kt)" > "$OUT/${TAG}_queue_gaps.txt" ;;
+  python3 $S gaps "$(db /tmp/p_kt)" 3 > "$OUT/${TAG}_queue_gaps.txt" ;;
 fw)
   rm -rf /tmp/p_f /tmp/p_w
   export GPUQR_SYNC_EVERY=${GPUQR_SYNC_EVERY:-512}

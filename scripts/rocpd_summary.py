@@ -101,43 +101,57 @@ def pmc(fetch_db, write_db, out_json, out_md, tag="dense", command=None):
 
 
 def gaps(db_path):
-    """Per hardware queue of the longest engine call in a --kernel-trace run: kernels, busy time, idle
-    time between kernels, and how long after the latest kernel end anywhere on the device each kernel
-    started (the start latency of a launch that waited for another queue's kernel)."""
+    """Per hardware queue, for every stage of ONE factorization in a --kernel-trace run of bench.py (by
+    default the timed step) and for the whole factorization: kernels, busy time, idle time between kernels, and how long after the
+    latest kernel end anywhere on the device each kernel started (the start latency of a launch that
+    waited for another queue's kernel)."""
     import bisect
     import collections
     import statistics
     db = sqlite3.connect(db_path)
     rows = [(short(n), s, e, q) for n, s, e, q in
             db.execute("select name, start, end, queue_id from kernels order by start") if short(n).startswith("k_")]
-    calls = [[rows[0]]]
-    for r in rows[1:]:
-        if r[1] - calls[-1][-1][2] > 3e6:           # engine calls are separated by milliseconds of host work
-            calls.append([])
-        calls[-1].append(r)
-    whole = [c for c in calls if len(c) >= 0.9 * max(len(x) for x in calls)]    # warm-up, timed and profiled steps
-    big = whole[1] if len(whole) > 1 else whole[0]                              # the timed one
-    print("window: one engine call = one stage of a staged factorization (calls are split where the device sits "
-          "idle for 3 ms of host work); of the %d calls in the trace, the second of those with the most kernels"
-          % len(calls))
-    print("kernels %d, span %.1f ms" % (len(big), (max(x[2] for x in big) - big[0][1]) / 1e6))
-    ends = sorted(x[2] for x in big)
-    byq = collections.defaultdict(list)
-    for x in big:
-        byq[x[3]].append(x)
-    for q, l in sorted(byq.items()):
-        l.sort(key=lambda x: x[1])
-        busy = sum(x[2] - x[1] for x in l)
-        idle = sum(max(0, l[i + 1][1] - l[i][2]) for i in range(len(l) - 1))
-        lat = []
-        for x in l:
-            i = bisect.bisect_right(ends, x[1]) - 1
-            if i >= 0:
-                lat.append(x[1] - ends[i])
-        names = collections.Counter(x[0] for x in l).most_common(2)
-        print("queue %d: %5d kernels, busy %.1f ms, idle between kernels %.1f ms, start latency median %.1f us, "
-              "sum %.1f ms  %s" % (q, len(l), busy / 1e6, idle / 1e6, statistics.median(lat) / 1e3 if lat else 0.0,
-                                   sum(lat) / 1e6, names))
+    # bench.py under the profiler runs NFACT factorizations with the same launches each (the first call, the
+    # timed steps, the profiled step): the last of them is the last 1/NFACT of the kernels; inside it every
+    # stage (group of fronts) starts with the launch that builds its S entries
+    nfact = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    which = int(sys.argv[4]) if len(sys.argv) > 4 else min(2, nfact)       # (bench.py: 1 the first call, 2 the timed step, 3 the profiled one)
+    per = len(rows) // nfact
+    lastf = rows[(which - 1) * per:which * per]
+    last = []
+    for r in lastf:
+        if r[0] == "k_build_s" or not last:
+            if not (last and all(x[0] == "k_build_s" for x in last[-1])):
+                last.append([])
+        last[-1].append(r)
+    print("window: factorization %d of the %d in the trace (%d of %d kernels; bench.py's timed step is the second, its "
+          "first call the first, its step with events around every launch the third), stage by stage (a stage starts "
+          "with the launch that builds its S entries)" % (which, nfact, len(lastf), len(rows)))
+
+    def report(title, ks):
+        print("%s: kernels %d, span %.1f ms" % (title, len(ks), (max(x[2] for x in ks) - ks[0][1]) / 1e6))
+        ends = sorted(x[2] for x in ks)
+        byq = collections.defaultdict(list)
+        for x in ks:
+            byq[x[3]].append(x)
+        for q, l in sorted(byq.items()):
+            l.sort(key=lambda x: x[1])
+            busy = sum(x[2] - x[1] for x in l)
+            idle = sum(max(0, l[i + 1][1] - l[i][2]) for i in range(len(l) - 1))
+            lat = []
+            for x in l:
+                i = bisect.bisect_right(ends, x[1]) - 1
+                if i >= 0:
+                    lat.append(x[1] - ends[i])
+            names = collections.Counter(x[0] for x in l).most_common(2)
+            print("  queue %d: %5d kernels, busy %.1f ms, idle between kernels %.1f ms, start latency median %.1f us, "
+                  "sum %.1f ms  %s" % (q, len(l), busy / 1e6, idle / 1e6, statistics.median(lat) / 1e3 if lat else 0.0,
+                                       sum(lat) / 1e6, names))
+
+    for k, c in enumerate(last):
+        report("stage %d" % (k + 1), c)
+    if len(last) > 1:
+        report("the whole factorization (idle includes the host work between the stages)", [x for c in last for x in c])
 
 
 if __name__ == "__main__":
