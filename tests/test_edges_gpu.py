@@ -319,3 +319,38 @@ def test_serial_debug_mode_gives_the_same_bits():
     finally:
         L.gpuqr_set_serial(0)
     assert (R0 != R1).nnz == 0
+
+
+@pytest.mark.parametrize("name", ["5x0", "0x4", "0x0", "allzero5x3", "1x1", "onecol", "onerow", "emptyrows"])
+def test_degenerate_sparse_matrices_through_the_numeric_driver(name):
+    """No columns, no rows, no entries, one entry, one column, one row, rows without entries: the analysis
+    and the numeric driver must come back with the structural rank, R of that many rows, and the dead
+    columns flagged (the reference's CPU path treats most of these as column singletons before its
+    multifrontal part and reports the same ranks: 0, 0, 0, 0, 1, 1, 1)."""
+    import scipy.sparse as sp
+    from suitesparse_amd import spqr
+    cases = {
+        "5x0": (sp.csc_matrix((5, 0)), 0), "0x4": (sp.csc_matrix((0, 4)), 0), "0x0": (sp.csc_matrix((0, 0)), 0),
+        "allzero5x3": (sp.csc_matrix((5, 3)), 0), "1x1": (sp.csc_matrix(np.array([[2.5]])), 1),
+        "onecol": (sp.csc_matrix(np.array([[1.], [2.], [0.], [3.]])), 1),
+        "onerow": (sp.csc_matrix(np.array([[1., 0., 2., 3.]])), 1),
+        "emptyrows": (sp.csc_matrix(np.array([[0., 0., 0.], [1., 2., 0.], [0., 0., 0.], [0., 3., 4.], [0., 0., 0.]])), 2),
+    }
+    A, rank = cases[name]
+    m, n = A.shape
+    sym = spqr.analyze(A, None, relax=-1, gpuMemorySize=2**30)
+    res = spqr.factorize(sym, A)
+    assert res.rank == rank
+    assert res.R.shape == (rank, n)
+    assert int(np.asarray(res.Rdead).sum()) == n - rank
+    # the same through the tolerance path (nothing here is numerically doubtful: same rank, same dead columns)
+    sym_rd = spqr.analyze(A, None, relax=-1, gpuMemorySize=2**30, rank_detection=True)
+    res_rd = spqr.factorize(sym_rd, A, tol=max(spqr.default_tol(A), 0.0))
+    assert res_rd.rank == rank and np.array_equal(np.asarray(res_rd.Rdead)[:n], np.asarray(res.Rdead)[:n])
+    if rank > 0:
+        # R'R = (A Qfill)'(A Qfill) on the live part: R is the factor of the columns in the order of Qfill
+        AQ = A[:, sym.Qfill[:n]].toarray()
+        R = res.R.toarray()
+        live = np.nonzero(np.asarray(res.Rdead)[:n] == 0)[0]
+        G = AQ.T @ AQ
+        assert np.abs((R.T @ R)[np.ix_(live, range(n))] - G[np.ix_(live, range(n))]).max() <= 1e-13 * max(1.0, np.abs(G).max())
